@@ -1,0 +1,131 @@
+/*
+ * pfa_hip.h -- C ABI of libpfa_hip.so: the MI355X (gfx950) Flash-Attention forward that
+ * replaces the body of the reference's electronic attention core.
+ *
+ * Reference seam (danieleschmidt/Photonic-Flash-Attention, all paths under
+ * src/photonic_flash_attention/):
+ *
+ *   pfa_fa3_fwd             replaces  core/flash_attention_3.py:120-150  _flash_attention_forward
+ *                                     = :152-180 _standard_attention + :182-262 _tiled_attention
+ *                                     (called from FlashAttention3.forward at :102)
+ *   pfa_fa3_args.softmax_scale         the `q = q * self.scaling` pass at :138, folded into the kernel
+ *   pfa_fa3_args.causal / seqlens_k /  the `attention_mask` argument (:165-168, :234-236): causal = 4-D
+ *     key_mask                         lower-triangular mask, seqlens_k / key_mask = 2-D [B,Sk] key mask
+ *   pfa_fa3_args.o strides             the `.transpose(1,2).contiguous()` copy at :107 (the kernel writes
+ *                                     [B,S,H,D] directly, so the copy disappears)
+ *   pfa_fa3_workspace_bytes           the tile-size memory budget of :264-293 (this path needs none)
+ *   pfa_device_supported              the `torch.cuda.is_available()` probes at :71,:142
+ *
+ * The reference has no native code, so nothing binds an FFI today; INTEGRATION.md
+ * shows the ctypes stub a maintainer adds at flash_attention_3.py:102.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every pointer is a DEVICE pointer owned by the caller;
+ *   - the library allocates nothing, frees nothing, keeps no reference after return;
+ *   - asynchronous: work is enqueued on `stream` (a hipStream_t passed as void*), no implicit sync;
+ *   - re-entrant and thread-safe: no mutable global state;
+ *   - returns PFA_OK (0) or a negative pfa_status; never aborts the process.
+ */
+#ifndef PFA_HIP_H
+#define PFA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFA_ABI_VERSION 1
+
+typedef enum pfa_status {
+    PFA_OK = 0,
+    PFA_ERR_NULL = -1,          /* required pointer is NULL                         */
+    PFA_ERR_STRUCT_SIZE = -2,   /* args->size does not match a known struct version */
+    PFA_ERR_SHAPE = -3,         /* B,H,Sq,Sk <= 0 or grid limits exceeded           */
+    PFA_ERR_HEAD_DIM = -4,      /* D not in {64, 128}                               */
+    PFA_ERR_DTYPE = -5,         /* dtype_in / dtype_out unsupported                 */
+    PFA_ERR_STRIDE = -6,        /* a stride is not a multiple of 8 elements         */
+    PFA_ERR_ALIGN = -7,         /* a base pointer is not 16-byte aligned            */
+    PFA_ERR_DEVICE = -8,        /* device is not gfx950 / cannot be selected        */
+    PFA_ERR_LAUNCH = -9,        /* hipLaunchKernel failed (see pfa_last_hip_error)  */
+    PFA_ERR_FLAGS = -10         /* unknown flag bits                                */
+} pfa_status;
+
+typedef enum pfa_dtype {
+    PFA_DTYPE_BF16 = 0,
+    PFA_DTYPE_FP16 = 1,
+    PFA_DTYPE_FP32 = 2          /* output only */
+} pfa_dtype;
+
+/* flags */
+#define PFA_FLAG_SPLIT_P   0x1u  /* carry P as bf16 hi+lo (two PV MFMA passes): the <=1e-3 parity mode        */
+#define PFA_FLAG_NO_XCD_MAP 0x2u /* debugging: identity block->work mapping                                  */
+
+/*
+ * One attention problem: O[b,i,h,:] = softmax_j(scale * <Q[b,i,h,:], K[b,j,h,:]> + mask) V[b,j,h,:]
+ *
+ * Tensors are addressed as base + b*stride_b + h*stride_h + s*stride_s + d (strides in ELEMENTS of the
+ * tensor's dtype, last dimension contiguous).  That covers [B,S,H,D] (what a fused QKV projection yields:
+ * q = qkv[..., 0:E] has stride_s = 3E, stride_h = D), [B,H,S,D], and slices of either.
+ */
+typedef struct pfa_fa3_args {
+    uint32_t size;              /* = sizeof(pfa_fa3_args); versions the struct       */
+    uint32_t flags;             /* PFA_FLAG_*                                        */
+
+    const void* q;              /* [B, Sq, H, D] by strides, dtype_in                */
+    const void* k;              /* [B, Sk, H, D]                                     */
+    const void* v;              /* [B, Sk, H, D]                                     */
+    void*       o;              /* [B, Sq, H, D], dtype_out                          */
+    float*      lse;            /* optional [B, H, Sq] fp32 natural-log LSE, or NULL */
+    const int32_t* seqlens_k;   /* optional [B]: keys >= seqlens_k[b] are masked     */
+    const uint8_t* key_mask;    /* optional [B, Sk] bytes, 0 = masked (2-D mask)     */
+
+    int64_t q_stride_b, q_stride_h, q_stride_s;
+    int64_t k_stride_b, k_stride_h, k_stride_s;
+    int64_t v_stride_b, v_stride_h, v_stride_s;
+    int64_t o_stride_b, o_stride_h, o_stride_s;
+    int64_t key_mask_stride_b;  /* bytes between batches of key_mask                 */
+
+    int32_t B, H, Sq, Sk, D;
+    int32_t dtype_in;           /* PFA_DTYPE_BF16 | PFA_DTYPE_FP16                   */
+    int32_t dtype_out;          /* = dtype_in, or PFA_DTYPE_FP32                     */
+    int32_t causal;             /* 1: key j visible to row i iff j <= i (top-left)   */
+    float   softmax_scale;      /* usually D^-0.5                                    */
+    int32_t device_id;          /* HIP device ordinal the pointers live on           */
+
+    void*   workspace;          /* pfa_fa3_workspace_bytes() bytes, may be NULL if 0 */
+    size_t  workspace_bytes;
+} pfa_fa3_args;
+
+/* ABI version of the loaded library (== PFA_ABI_VERSION of the header it was built from). */
+int pfa_abi_version(void);
+
+/* Human-readable text for a pfa_status. */
+const char* pfa_status_string(int status);
+
+/* 1 if HIP device `device_id` is a gfx950 part this library has code for, 0 if not, <0 on error. */
+int pfa_device_supported(int device_id);
+
+/* Last hipError_t seen by a failing call on this thread (0 = hipSuccess). */
+int pfa_last_hip_error(void);
+
+/* Scratch bytes pfa_fa3_fwd needs for `a` (currently always 0; kept so callers need not change). */
+size_t pfa_fa3_workspace_bytes(const pfa_fa3_args* a);
+
+/* Validate `a` without launching: PFA_OK or the error pfa_fa3_fwd would return. */
+int pfa_fa3_check(const pfa_fa3_args* a);
+
+/* Enqueue the forward on `stream` (hipStream_t as void*, NULL = default stream). */
+int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream);
+
+/*
+ * Kernel-selection introspection for tests/bench: writes the name of the kernel variant pfa_fa3_fwd
+ * would launch for `a` into buf (NUL terminated, truncated to n) and returns the number of workgroups.
+ */
+int pfa_fa3_describe(const pfa_fa3_args* a, char* buf, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFA_HIP_H */

@@ -1,0 +1,133 @@
+"""Host side of the hot path: tensor -> C-ABI argument marshalling for ``pfa_fa3_fwd``.
+
+``fa3_forward`` has the call shape of the reference seam
+``FlashAttention3._flash_attention_forward(q, k, v, attention_mask, need_weights)``
+(core/flash_attention_3.py:120-150): operands are ``[B, H, S, D]`` tensors (usually strided
+views of the fused QKV projection, :97-99), the result is ``[B, H, Sq, D]``.  The kernel
+reads the views in place and writes a ``[B, Sq, H, D]`` buffer, returned as the transposed
+view, so the reference's ``.transpose(1, 2).contiguous()`` at :107 costs nothing.
+
+No fallback lives here: unsupported arguments raise ``ValueError`` (pre-launch
+``pfa_status``) or ``PfaError``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _capi
+
+_DT = {torch.bfloat16: _capi.PFA_DTYPE_BF16, torch.float16: _capi.PFA_DTYPE_FP16, torch.float32: _capi.PFA_DTYPE_FP32}
+
+SUPPORTED_HEAD_DIMS = (64, 128)
+
+
+def is_available(device: Optional[torch.device] = None) -> bool:
+    """True when the native library is present and ``device`` is a gfx950 GPU."""
+    if not torch.cuda.is_available():
+        return False
+    try:
+        lib = _capi.load()
+    except OSError:
+        return False
+    idx = torch.cuda.current_device() if device is None or device.index is None else device.index
+    return lib.pfa_device_supported(int(idx)) == 1
+
+
+def _bhsd_strides(t: torch.Tensor):
+    sb, sh, ss, sd = t.stride()
+    if sd != 1 and t.shape[3] != 1:
+        raise ValueError("last (head_dim) stride must be 1")
+    return sb, sh, ss
+
+
+def build_args(q, k, v, out, *, causal=False, seqlens_k=None, key_mask=None, softmax_scale=None,
+               lse=None, split_p=False):
+    """Fill a ``pfa_fa3_args`` from ``[B,H,S,D]``-shaped (arbitrarily strided) tensors."""
+    B, H, Sq, D = q.shape
+    Sk = k.shape[2]
+    if k.shape != (B, H, Sk, D) or v.shape != (B, H, Sk, D):
+        raise ValueError(f"shape mismatch: q {tuple(q.shape)} k {tuple(k.shape)} v {tuple(v.shape)}")
+    if out.shape != (B, H, Sq, D):
+        raise ValueError("output shape mismatch")
+    if q.dtype not in (torch.bfloat16, torch.float16) or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise ValueError("q, k, v must share dtype bf16 or fp16")
+    if out.dtype not in (q.dtype, torch.float32):
+        raise ValueError("output dtype must be the input dtype or fp32")
+    if not (q.is_cuda and k.is_cuda and v.is_cuda and out.is_cuda):
+        raise ValueError("pfa_fa3_fwd needs device tensors (there is no CPU path)")
+    qs, ks, vs, os_ = (_bhsd_strides(t) for t in (q, k, v, out))
+    a = _capi.make_args(
+        flags=_capi.PFA_FLAG_SPLIT_P if split_p else 0,
+        q=q.data_ptr(), k=k.data_ptr(), v=v.data_ptr(), o=out.data_ptr(),
+        q_stride_b=qs[0], q_stride_h=qs[1], q_stride_s=qs[2],
+        k_stride_b=ks[0], k_stride_h=ks[1], k_stride_s=ks[2],
+        v_stride_b=vs[0], v_stride_h=vs[1], v_stride_s=vs[2],
+        o_stride_b=os_[0], o_stride_h=os_[1], o_stride_s=os_[2],
+        B=B, H=H, Sq=Sq, Sk=Sk, D=D,
+        dtype_in=_DT[q.dtype], dtype_out=_DT[out.dtype], causal=1 if causal else 0,
+        softmax_scale=float(D ** -0.5 if softmax_scale is None else softmax_scale),
+        device_id=q.device.index if q.device.index is not None else torch.cuda.current_device(),
+    )
+    keep = []
+    if seqlens_k is not None:
+        sl = torch.as_tensor(seqlens_k, dtype=torch.int32, device=q.device).contiguous()
+        if sl.numel() != B:
+            raise ValueError("seqlens_k must have B entries")
+        a.seqlens_k = sl.data_ptr()
+        keep.append(sl)
+    if key_mask is not None:
+        km = key_mask
+        if km.shape != (B, Sk):
+            raise ValueError("key_mask must be [B, Sk]")
+        km = (km != 0).to(device=q.device, dtype=torch.uint8).contiguous()
+        a.key_mask = km.data_ptr()
+        a.key_mask_stride_b = km.stride(0)
+        keep.append(km)
+    if lse is not None:
+        if lse.shape != (B, H, Sq) or lse.dtype != torch.float32 or not lse.is_contiguous():
+            raise ValueError("lse must be contiguous fp32 [B, H, Sq]")
+        a.lse = lse.data_ptr()
+    return a, keep
+
+
+def fa3_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: bool = False,
+                seqlens_k=None, key_mask: Optional[torch.Tensor] = None,
+                softmax_scale: Optional[float] = None, out_dtype: Optional[torch.dtype] = None,
+                return_lse: bool = False, split_p: Optional[bool] = None,
+                out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """softmax(scale * q k^T + mask) v on the MI355X kernel.
+
+    q: ``[B,H,Sq,D]``, k/v: ``[B,H,Sk,D]`` (any batch/head/seq strides that are multiples of 8
+    elements; head_dim contiguous).  Returns ``(out [B,H,Sq,D] view of a [B,Sq,H,D] buffer, lse or None)``.
+
+    ``out_dtype=torch.float32`` selects the parity variant: fp32 store and, unless
+    ``split_p=False`` is forced, P carried as bf16 hi+lo so the result is within 1e-3 of the
+    fp32 reference ("numerics").
+    """
+    B, H, Sq, D = q.shape
+    odt = q.dtype if out_dtype is None else out_dtype
+    if split_p is None:
+        split_p = odt == torch.float32
+    if out is None:
+        out = torch.empty((B, Sq, H, D), dtype=odt, device=q.device).permute(0, 2, 1, 3)
+    lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device) if return_lse else None
+    args, keep = build_args(q, k, v, out, causal=causal, seqlens_k=seqlens_k, key_mask=key_mask,
+                            softmax_scale=softmax_scale, lse=lse, split_p=split_p)
+    stream = torch.cuda.current_stream(q.device).cuda_stream
+    st = _capi.load().pfa_fa3_fwd(C.byref(args), C.c_void_p(stream))
+    if st in (-3, -4, -5, -6, -7, -10):
+        raise ValueError(f"pfa_fa3_fwd: {_capi.status_string(st)}")
+    _capi.check_status(st)
+    for t in keep:   # tensors made here must outlive the enqueued kernel
+        t.record_stream(torch.cuda.current_stream(q.device))
+    return out, lse
+
+
+def fa3_forward_bshd(q, k, v, **kw):
+    """Same, for operands laid out ``[B,S,H,D]``; returns ``[B,Sq,H,D]`` (+ lse)."""
+    o, lse = fa3_forward(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), **kw)
+    return o.permute(0, 2, 1, 3), lse

@@ -1,0 +1,186 @@
+"""GPU parity tests: the HIP kernel, called through the C ABI, against
+(1) outputs of the real reference (tests/golden) and (2) the CPU oracle on seeded inputs.
+
+Tolerances (DESIGN.md "numerics"):
+  * PARITY variant (fp32 store, P as bf16 hi+lo):   max-abs <= 1e-3   (north_star bar)
+  * FAST variant  (bf16/fp16 store, P single bf16): |err| <= 2^-8*|ref| + 2^-7   (bf16 rounding of
+    P and of the output; the bound is loose on purpose, the measured numbers are printed)
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_inputs, golden_names, load_golden
+
+pytestmark = pytest.mark.gpu
+
+PARITY_TOL = 1e-3
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _run(q, k, v, **kw):
+    from photonic_flash_attention_amd import ops
+    dev = _dev()
+    o, lse = ops.fa3_forward_bshd(q.to(dev), k.to(dev), v.to(dev), **kw)
+    torch.cuda.synchronize()
+    return o.float().cpu(), (None if lse is None else lse.cpu())
+
+
+def _fast_ok(out, ref):
+    return bool(((out - ref).abs() <= ref.abs() * 2 ** -8 + 2 ** -7).all())
+
+
+def test_library_loaded_and_device_supported(hip):
+    lib = hip.load()
+    assert lib.pfa_abi_version() == hip.PFA_ABI_VERSION
+    assert lib.pfa_device_supported(0) == 1
+
+
+@pytest.mark.parametrize("name", golden_names("full"))
+def test_golden_full(name):
+    meta, arr = load_golden(name)
+    if meta["D"] not in (64, 128):
+        pytest.skip("head dim outside kernel domain")
+    q, k, v = golden_inputs(meta)
+    ref = torch.from_numpy(arr["out"])
+    lens = None if meta["kv_valid"] is None else [meta["kv_valid"]] * meta["B"]
+    out, _ = _run(q, k, v, causal=meta["causal"], seqlens_k=lens, out_dtype=torch.float32)
+    err = float((out - ref).abs().max())
+    print(f"{name}: parity variant max-abs {err:.3e}")
+    assert err <= PARITY_TOL
+    out16, _ = _run(q, k, v, causal=meta["causal"], seqlens_k=lens)
+    print(f"{name}: fast variant max-abs {float((out16 - ref).abs().max()):.3e}")
+    assert _fast_ok(out16, ref)
+
+
+@pytest.mark.parametrize("name", golden_names("sampled"))
+def test_golden_sampled_baseline_shapes(name):
+    """BASELINE.json configs C2..C5 at full size: sampled rows + whole-head sums of the reference."""
+    meta, arr = load_golden(name)
+    q, k, v = golden_inputs(meta)
+    rows = torch.from_numpy(arr["rows"])
+    out, _ = _run(q, k, v, causal=meta["causal"], out_dtype=torch.float32)
+    out16, _ = _run(q, k, v, causal=meta["causal"])
+    for i, (b, h) in enumerate(meta["heads"]):
+        ref = torch.from_numpy(arr["out"][i])
+        err = float((out[b, rows, h] - ref).abs().max())
+        print(f"{name} head {(b, h)}: parity max-abs {err:.3e}; fast {float((out16[b, rows, h] - ref).abs().max()):.3e}")
+        assert err <= PARITY_TOL
+        assert _fast_ok(out16[b, rows, h], ref)
+        hs = float(out[b, :, h].double().sum())
+        assert abs(hs - arr["head_sum"][i]) <= 2e-5 * arr["head_abs_sum"][i] + 1e-2
+
+
+CASES = [
+    # B, H, Sq, Sk, D, causal, seqlens
+    (1, 1, 1, 1, 64, False, None),
+    (1, 2, 33, 33, 128, True, None),
+    (2, 3, 255, 257, 64, False, None),
+    (2, 2, 256, 256, 128, True, None),
+    (1, 2, 300, 1000, 128, False, [777]),
+    (3, 2, 513, 513, 64, True, [513, 100, 1]),
+    (1, 4, 1024, 1024, 128, True, None),
+    (2, 1, 700, 64, 128, False, [64, 63]),
+    (1, 2, 64, 2048, 64, False, None),
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", CASES)
+def test_vs_oracle(case, dtype):
+    from oracle import fa3_oracle as orc
+    from photonic_flash_attention_amd import synth
+    B, H, Sq, Sk, D, causal, lens = case
+    q, k, v = synth.qkv(B, H, Sq, Sk, D, 31 + Sq + Sk, dtype)
+    ref = orc.attention_bshd(q, k, v, causal=causal, seqlens_k=lens)
+    out, lse = _run(q, k, v, causal=causal, seqlens_k=lens, out_dtype=torch.float32, return_lse=True)
+    err = float((out - ref).abs().max())
+    assert err <= PARITY_TOL, f"{case} {dtype}: {err}"
+    ref_lse = orc.lse_bshd(q, k, causal=causal, seqlens_k=lens)
+    assert float((lse - ref_lse).abs().max()) <= 2e-3
+    out16, _ = _run(q, k, v, causal=causal, seqlens_k=lens)
+    assert _fast_ok(out16, ref)
+
+
+def test_strided_views_of_fused_qkv():
+    """q,k,v as strided views of one [B,S,3E] buffer (flash_attention_3.py:88-99)."""
+    from oracle import fa3_oracle as orc
+    from photonic_flash_attention_amd import ops, synth
+    B, S, H, D = 2, 384, 4, 64
+    E = H * D
+    qkv = torch.from_numpy(synth.normal_f32((B, S, 3 * E), 5)).to(torch.bfloat16)
+    dev = _dev()
+    g = qkv.to(dev)
+    qv, kv, vv = (t.view(B, S, H, D).transpose(1, 2) for t in g.chunk(3, dim=-1))
+    o, _ = ops.fa3_forward(qv, kv, vv, out_dtype=torch.float32)
+    assert o.transpose(1, 2).is_contiguous()
+    qc, kc, vc = (t.view(B, S, H, D) for t in qkv.chunk(3, dim=-1))
+    ref = orc.attention_bshd(qc, kc, vc)
+    assert float((o.transpose(1, 2).cpu() - ref).abs().max()) <= PARITY_TOL
+
+
+def test_key_mask_2d():
+    from oracle import fa3_oracle as orc
+    from photonic_flash_attention_amd import synth
+    B, H, S, D = 2, 2, 320, 64
+    q, k, v = synth.qkv(B, H, S, S, D, 91, "bf16")
+    g = torch.Generator().manual_seed(3)
+    km = torch.rand(B, S, generator=g) > 0.3
+    km[:, 0] = True
+    mask4 = km.view(B, 1, 1, S).expand(B, 1, S, S)
+    ref = orc.flash_attention_forward(q.float().permute(0, 2, 1, 3), k.float().permute(0, 2, 1, 3),
+                                      v.float().permute(0, 2, 1, 3), mask4).permute(0, 2, 1, 3)
+    out, _ = _run(q, k, v, key_mask=km, out_dtype=torch.float32)
+    assert float((out - ref).abs().max()) <= PARITY_TOL
+
+
+def test_fully_masked_rows_are_zero():
+    from photonic_flash_attention_amd import synth
+    q, k, v = synth.qkv(1, 1, 64, 64, 64, 9, "bf16")
+    out, lse = _run(q, k, v, seqlens_k=[0], return_lse=True)
+    assert float(out.abs().max()) == 0.0 and bool(torch.isinf(lse).all())
+
+
+def test_online_softmax_rescale_branch_is_forced():
+    """cdna guide rule 26: spike one key per row late in the sequence so the running max jumps
+    at a chosen tile; an fp64 full-tensor reference checks the rescale path."""
+    from photonic_flash_attention_amd import synth
+    B, H, S, D = 1, 2, 1024, 128
+    q, k, v = synth.qkv(B, H, S, S, D, 123, "bf16")
+    k = k.clone()
+    k[:, 700] = (q[:, 5] * 4).to(torch.bfloat16)    # row 5 (and friends) spike at key 700 (tile 10)
+    k[:, 130] = (q[:, 900] * 3).to(torch.bfloat16)
+    qd, kd, vd = (t.double().permute(0, 2, 1, 3) for t in (q, k, v))
+    ref = torch.softmax(qd @ kd.transpose(-1, -2) * D ** -0.5, dim=-1) @ vd
+    out, _ = _run(q, k, v, out_dtype=torch.float32)
+    assert float((out - ref.permute(0, 2, 1, 3).float()).abs().max()) <= PARITY_TOL
+
+
+def test_scaled_inputs_stay_finite():
+    """tests/unit/test_flash_attention_3.py:249-262: x10 (bf16) / x5 (fp16) scaled inputs."""
+    from photonic_flash_attention_amd import synth
+    for dtype, sc in (("bf16", 10.0), ("fp16", 5.0)):
+        q, k, v = synth.qkv(2, 4, 256, 256, 64, 17, dtype, scale=sc)
+        out, _ = _run(q, k, v)
+        assert bool(torch.isfinite(out).all())
+
+
+def test_bad_arguments_raise_before_launch():
+    from photonic_flash_attention_amd import ops
+    dev = _dev()
+    q = torch.zeros(1, 2, 16, 80, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(ValueError):
+        ops.fa3_forward(q, q, q)                      # head dim 80
+    q32 = torch.zeros(1, 2, 16, 64, dtype=torch.float32, device=dev)
+    with pytest.raises(ValueError):
+        ops.fa3_forward(q32, q32, q32)                # fp32 inputs
+    qc = torch.zeros(1, 2, 16, 64, dtype=torch.bfloat16)
+    with pytest.raises(ValueError):
+        ops.fa3_forward(qc, qc, qc)                   # host tensors: no CPU path
