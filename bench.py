@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json: attention TFLOP/s + ms/fwd at
+B=4 S=4096 H=16 D=128, 1/2/4/8 GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE forward of the MI355X kernel (through the C ABI) over one batch of synthetic
+Q/K/V already resident in HBM: BASELINE config C3 (B=4, S=4096, H=16, D=128, bf16, causal) per
+GPU.  With N GPUs every rank owns its own B=4 shard of a global batch B=4N (batch x head sharding,
+SURVEY.md section 8(e)); the path has no data-path collective, so scaling is "weak".  The north
+star's single RCCL gather of the outputs runs ONCE after the timed region and is reported
+separately (``gather``), together with a second, secondary loop that overlaps one gather per
+forward on a side stream (``end_to_end``).
+
+FLOP convention: 4*B*H*Sq*Sk*D, halved for causal.
+Rank 0 prints ONE JSON line.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+MFMA_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level table)
+
+WORKLOADS = {
+    # name: (B per GPU, H, S, D, causal)
+    "C3": (4, 16, 4096, 128, True),     # headline: BASELINE.json configs[2]
+    "C4": (4, 16, 4096, 128, False),    # configs[3] per-GPU shard (B=32 over 8 GPUs)
+    "C2": (4, 12, 1024, 64, False),
+    "C5": (1, 32, 16384, 128, True),
+}
+
+
+def flops(B, H, S, D, causal):
+    f = 4.0 * B * H * S * S * D
+    return f / 2 if causal else f
+
+
+def cpu_baseline(B, H, S, D, causal):
+    """The oracle (our CPU restatement of the reference's fp32 path, kind "port") timed on this
+    host's cores on a bounded sample of the same workload: one batch element (all H heads)."""
+    from oracle import fa3_oracle as orc
+    from photonic_flash_attention_amd import synth
+
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores)
+    q, k, v = synth.qkv(1, H, S, S, D, 1234, "bf16")
+    ts = []
+    for i in range(3):
+        t0 = time.perf_counter()
+        orc.attention_bshd(q, k, v, causal=causal)
+        ts.append(time.perf_counter() - t0)
+        if sum(ts) > 45:
+            break
+    t = statistics.median(ts[1:] or ts)
+    return {
+        "value": round(flops(1, H, S, D, causal) / t / 1e12, 5),
+        "unit": "TFLOP/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"1 of the {B} batch elements (B=1,H={H},S={S},D={D},causal={causal}), fp32 on bf16-rounded "
+                  f"inputs, torch {torch.get_num_threads()} threads, median of {max(1, len(ts) - 1)} after 1 warm-up, "
+                  f"{t * 1e3:.0f} ms; the reference computes masked causal tiles in full "
+                  f"({flops(1, H, S, D, False) / t / 1e12:.4f} TFLOP/s against the un-halved count)",
+    }
+
+
+def parity_check(q, k, v, causal, heads):
+    """Benched kernel (bf16 store) and parity variant (fp32 store, split P) vs the oracle on a few heads."""
+    from oracle import fa3_oracle as orc
+    from photonic_flash_attention_amd import ops
+    o16, _ = ops.fa3_forward_bshd(q, k, v, causal=causal)
+    o32, _ = ops.fa3_forward_bshd(q, k, v, causal=causal, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    e16 = e32 = 0.0
+    for (b, h) in heads:
+        sl = (slice(b, b + 1), slice(None), slice(h, h + 1))
+        ref = orc.attention_bshd(q[sl].cpu(), k[sl].cpu(), v[sl].cpu(), causal=causal)
+        e16 = max(e16, float((o16[sl].float().cpu() - ref).abs().max()))
+        e32 = max(e32, float((o32[sl].cpu() - ref).abs().max()))
+    return e16, e32
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} ...`")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (there is no CPU path to time)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    from photonic_flash_attention_amd import _capi, ops
+    from photonic_flash_attention_amd.parallel import sharded
+
+    _capi.load()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    B, H, S, D, causal = WORKLOADS[args.workload]
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    q, k, v = (torch.randn(B, S, H, D, device=dev, dtype=torch.float32, generator=gen).to(torch.bfloat16)
+               for _ in range(3))
+    out = torch.empty(B, S, H, D, device=dev, dtype=torch.bfloat16)
+    outv = out.permute(0, 2, 1, 3)
+    qv, kv, vv = (t.permute(0, 2, 1, 3) for t in (q, k, v))
+
+    def step():
+        ops.fa3_forward(qv, kv, vv, causal=causal, out=outv)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # ---- timed region: exactly K steps, HIP events on the launch stream + host clock ------------------
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / args.steps      # average launch-to-launch kernel duration
+    tmax = torch.tensor([wall], device=dev, dtype=torch.float64)
+    kmax = torch.tensor([kern_ms], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
+    wall = float(tmax)
+    ms_per_step = wall / args.steps * 1e3
+    f_rank = flops(B, H, S, D, causal)
+    value = f_rank * world / (wall / args.steps) / 1e12
+
+    # ---- the single gather at the end (outside the timed steps) + overlapped end-to-end loop --------------
+    gather = end_to_end = None
+    if world > 1:
+        gathered, g_ms = sharded.gather_outputs(out, timed=True)
+        assert gathered.shape[0] == B * world
+        gather = {"ms": round(g_ms, 4), "bytes_per_rank": out.numel() * out.element_size(),
+                  "algo": sharded.GATHER_ALGO}
+        e2e_ms = sharded.overlapped_forward_gather(step, out, args.steps)
+        t = torch.tensor([e2e_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        end_to_end = {"ms_per_step": round(float(t), 4),
+                      "value": round(f_rank * world / (float(t) * 1e-3) / 1e12, 2), "unit": "TFLOP/s"}
+
+    if rank == 0:
+        name, nwg = _capi.describe(ops.build_args(qv, kv, vv, outv, causal=causal)[0])
+        achieved = f_rank / (float(kmax) * 1e-3) / 1e12
+        line = {
+            "metric": "attention_fwd_tflops", "value": round(value, 2), "unit": "TFLOP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: B={B}/GPU S={S} H={H} D={D} bf16 "
+                                   f"{'causal' if causal else 'non-causal'} (BASELINE.json configs[2] headline shape)",
+                       "global_batch": B * world, "seq_len": S, "heads": H, "head_dim": D, "causal": causal,
+                       "sharding": f"batch x head over {world} rank(s), no data-path collective",
+                       "flop_convention": "4*B*H*S*S*D, halved for causal", "kernel": name, "workgroups": nwg},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel_ms": round(float(kmax), 4),
+                         "hbm_algorithmic_GBps": round(2 * 2 * 2 * B * H * S * D / (float(kmax) * 1e-3) / 1e9, 1)},
+        }
+        if gather:
+            line["gather"] = gather
+            line["end_to_end"] = end_to_end
+        if not args.no_parity:
+            e16, e32 = parity_check(q, k, v, causal, [(0, 0), (B - 1, H - 1)])
+            line["parity"] = {"benched_kernel_bf16_out_max_abs": round(e16, 6),
+                              "parity_variant_fp32_out_max_abs": round(e32, 8), "heads_checked": 2,
+                              "oracle": "oracle/fa3_oracle.py (pinned by tests/golden)"}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(B, H, S, D, causal)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,164 @@
+"""``FlashAttention3``: the reference's electronic attention module on the MI355X kernel.
+
+Mirror of ``core/flash_attention_3.py:11-302`` of the reference: same constructor, same
+parameter names/shapes (``qkv_proj.weight [3E,E]``, ``out_proj.weight [E,E]`` so existing
+state dicts load), same ``forward`` signature and always-a-2-tuple return (:118).  What
+changes is everything between the two projections:
+
+* the core seam ``_flash_attention_forward`` (:120-150) is ONE call into ``libpfa_hip.so``
+  (``ops.fa3_forward``) instead of the eager dense / 512-tile loops (:152-262);
+* q/k/v are consumed as the strided views of the fused projection (:97-99) and the output is
+  written ``[B,S,H,D]``, so the ``q * scaling`` pass (:138) and the ``.contiguous()`` copy
+  (:107) disappear;
+* self-attention is recognised by identity (``key is None or key is query``), not by two
+  full-tensor ``torch.equal`` compares that force a host sync (:86); both branches compute
+  the same numbers, only the GEMM count differs;
+* the per-call ``torch.cuda.synchronize()`` (:114) is opt-in (``GlobalConfig.enable_profiling``).
+
+There is no eager/CPU implementation in this class: host tensors, missing library or an
+unsupported argument raise.
+"""
+
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..config import get_config
+
+
+class FlashAttention3(nn.Module):
+    """Electronic ("gpu") attention branch: QKV projection -> HIP flash forward -> out projection."""
+
+    def __init__(
+        self,
+        embed_dim: int,
+        num_heads: int,
+        dropout: float = 0.0,
+        bias: bool = True,
+        device: Optional[torch.device] = None,
+        dtype: Optional[torch.dtype] = None,
+    ):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.dropout = dropout
+        self.head_dim = embed_dim // num_heads
+        assert self.head_dim * num_heads == embed_dim, "embed_dim must be divisible by num_heads"
+        self.scaling = self.head_dim ** -0.5
+
+        self.qkv_proj = nn.Linear(embed_dim, 3 * embed_dim, bias=bias, device=device, dtype=dtype)
+        self.out_proj = nn.Linear(embed_dim, embed_dim, bias=bias, device=device, dtype=dtype)
+        self.dropout_module = nn.Dropout(dropout) if dropout > 0 else None
+
+        # fp32 modules compute attention in this dtype (MFMA has no fast fp32 path on gfx950)
+        self.compute_dtype = torch.bfloat16
+        self.last_latency_ms = 0.0
+        self.last_memory_mb = 0.0
+
+    # ------------------------------------------------------------------ forward
+    def forward(
+        self,
+        query: torch.Tensor,
+        key: Optional[torch.Tensor] = None,
+        value: Optional[torch.Tensor] = None,
+        attention_mask: Optional[torch.Tensor] = None,
+        need_weights: bool = False,
+        is_causal: bool = False,
+    ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """query/key/value: ``[B, S, E]``.  Returns ``(output [B,S,E], weights or None)``.
+
+        ``attention_mask``: ``None`` or a 2-D ``[B, Sk]`` key mask (0 = masked).  Causality,
+        which the reference can only express as a dense 4-D mask, is the ``is_causal`` flag here
+        (an addition to the reference signature); other 4-D masks are not yet supported."""
+        profile = get_config().enable_profiling and query.is_cuda
+        if profile:
+            start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            start.record()
+
+        batch_size, seq_len, embed_dim = query.shape
+        self_attn = (key is None or key is query) and (value is None or value is query)
+        if self_attn:
+            q, k, v = self.qkv_proj(query).chunk(3, dim=-1)
+        else:
+            key = query if key is None else key
+            value = query if value is None else value
+            w, b = self.qkv_proj.weight, self.qkv_proj.bias
+            e = embed_dim
+            lin = nn.functional.linear
+            q = lin(query, w[:e], None if b is None else b[:e])
+            if key is value:
+                k, v = lin(key, w[e:], None if b is None else b[e:]).chunk(2, dim=-1)
+            else:
+                k = lin(key, w[e:2 * e], None if b is None else b[e:2 * e])
+                v = lin(value, w[2 * e:], None if b is None else b[2 * e:])
+
+        q = q.view(batch_size, seq_len, self.num_heads, self.head_dim).transpose(1, 2)
+        k = k.view(batch_size, -1, self.num_heads, self.head_dim).transpose(1, 2)
+        v = v.view(batch_size, -1, self.num_heads, self.head_dim).transpose(1, 2)
+
+        attn_output, attn_weights = self._flash_attention_forward(
+            q, k, v, attention_mask, need_weights, is_causal=is_causal)
+
+        # [B,H,S,D] view of a [B,S,H,D] buffer: this transpose+contiguous is free
+        attn_output = attn_output.transpose(1, 2).contiguous().view(batch_size, seq_len, embed_dim)
+        output = self.out_proj(attn_output.to(self.out_proj.weight.dtype))
+
+        if profile:
+            end.record()
+            torch.cuda.synchronize()
+            self.last_latency_ms = start.elapsed_time(end)
+            self.last_memory_mb = torch.cuda.max_memory_allocated() / 1024 / 1024
+        return output, attn_weights if need_weights else None
+
+    # ------------------------------------------------------------------ core seam
+    def _flash_attention_forward(
+        self,
+        q: torch.Tensor,
+        k: torch.Tensor,
+        v: torch.Tensor,
+        attention_mask: Optional[torch.Tensor] = None,
+        need_weights: bool = False,
+        is_causal: bool = False,
+    ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """q,k,v: ``[B,H,S,D]`` (strided views are fine).  The replaced seam (:120-150)."""
+        if not q.is_cuda:
+            raise RuntimeError(
+                "FlashAttention3 runs on MI355X only: move the module and its inputs to a GPU "
+                "(this package ships no CPU or eager implementation of the core)")
+        if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+            raise RuntimeError("forward-only kernel: call under torch.no_grad() (backward is not implemented)")
+        if self.training and self.dropout > 0:
+            raise NotImplementedError("attention dropout in training mode is not implemented on the HIP path")
+        if need_weights:
+            raise NotImplementedError("need_weights=True is not implemented on the HIP path yet")
+
+        key_mask = None
+        if attention_mask is not None:
+            if attention_mask.dim() == 2:
+                key_mask = attention_mask
+            else:
+                raise NotImplementedError(
+                    "only 2-D [B,Sk] key masks and is_causal=True are supported; got a "
+                    f"{attention_mask.dim()}-D attention_mask")
+
+        io_dtype = q.dtype
+        if io_dtype == torch.float32:
+            cd = self.compute_dtype
+            out, _ = ops.fa3_forward(q.to(cd), k.to(cd), v.to(cd), causal=is_causal, key_mask=key_mask,
+                                     softmax_scale=self.scaling, out_dtype=torch.float32)
+        else:
+            out, _ = ops.fa3_forward(q, k, v, causal=is_causal, key_mask=key_mask, softmax_scale=self.scaling)
+        return out, None
+
+    def get_performance_stats(self) -> dict:
+        """Same keys as the reference (:295-302)."""
+        return {
+            "latency_ms": self.last_latency_ms,
+            "memory_mb": self.last_memory_mb,
+            "device": "cuda",
+            "implementation": "flash_attention_3",
+        }

@@ -37,6 +37,23 @@ def test_oracle_matches_reference_sampled(name):
         assert abs(float(out.double().sum()) - arr["head_sum"][i]) <= 1e-6 * arr["head_abs_sum"][i] + 1e-3
 
 
+@pytest.mark.parametrize("name", golden_names("full"))
+def test_c_restatement_matches_reference_full(name):
+    """oracle/fa3_oracle.c (plain C, no BLAS) against the same reference outputs."""
+    import os
+    import subprocess
+    from conftest import REPO
+    from oracle import c_oracle
+    if not os.path.exists(os.path.join(REPO, "oracle", "liboracle_fa3.so")):
+        subprocess.run(["make", "-C", os.path.join(REPO, "oracle")], check=True)
+    meta, arr = load_golden(name)
+    q, k, v = golden_inputs(meta)
+    lens = None if meta["kv_valid"] is None else [meta["kv_valid"]] * meta["B"]
+    out = c_oracle.attention_bshd(q, k, v, causal=meta["causal"], seqlens_k=lens)
+    err = float((out - torch.from_numpy(arr["out"])).abs().max())
+    assert err <= 5e-6, f"{name}: {err}"
+
+
 def test_oracle_module_plumbing():
     meta, arr = load_golden("g1_c1_module")
     E, H, seed = meta["E"], meta["H"], meta["seed"]
