@@ -55,7 +55,9 @@ def cpu_baseline(B, H, S, D, causal):
     from oracle import fa3_oracle as orc
     from photonic_flash_attention_amd import synth
 
-    cores = len(os.sched_getaffinity(0))
+    # the GPU box exposes every host core in the affinity mask but a 1-GPU job owns a 16-core share;
+    # oversubscribing (256 threads) made this leg 50x slower, so the thread count is capped and stated
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("PFA_CPU_THREADS", "16")))
     torch.set_num_threads(cores)
     q, k, v = synth.qkv(1, H, S, S, D, 1234, "bf16")
     ts = []
