@@ -61,6 +61,7 @@ typedef enum pfa_dtype {
 /* flags */
 #define PFA_FLAG_SPLIT_P   0x1u  /* carry P as bf16 hi+lo (two PV MFMA passes): the <=1e-3 parity mode        */
 #define PFA_FLAG_NO_XCD_MAP 0x2u /* debugging: identity block->work mapping                                  */
+#define PFA_FLAG_VARIANT_MASK 0xff00u /* development: experimental kernel variant id in bits 8..15 (0 = default) */
 
 /*
  * One attention problem: O[b,i,h,:] = softmax_j(scale * <Q[b,i,h,:], K[b,j,h,:]> + mask) V[b,j,h,:]

@@ -101,6 +101,14 @@ __device__ __forceinline__ uint32_t tile_off(uint32_t key, uint32_t ch) {
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// One v_max3_f32.  fmaxf() on MFMA results makes hipcc emit a canonicalising v_max_f32 x,x per operand
+// (3 VALU per 2 values instead of 0.5); the scores are never sNaN, so the raw instruction is safe.
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // max(x[lane], x[lane ^ 32]) in every lane: the two lanes that share a query row.
 __device__ __forceinline__ float row_pair_max(float x) {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -111,21 +119,33 @@ __device__ __forceinline__ float row_pair_sum(float x) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <typename T, int D, bool CAUSAL, bool SPLITP, typename OT>
+// Variant bits (compile-time), selected through pfa_fa3_args.flags >> 8 for A/B runs:
+constexpr int VAR_DEFER_MAX = 1;   // T13: rescale O only when a row max grew by > 2^8 (else exact lazy rescale)
+constexpr int VAR_SETPRIO = 2;     // s_setprio(1) around the MFMA clusters
+constexpr int VAR_SCHED = 4;       // pin the QK^T read/MFMA interleave with sched_group_barrier
+constexpr int VAR_GLDS = 8;        // K/V tiles by LDS-DMA (global_load_lds_dwordx4), swizzle on the source address
+constexpr int VAR_DEFAULT = VAR_DEFER_MAX;
+
+template <int N> struct IC { static constexpr int value = N; };
+
+template <typename T, int D, bool CAUSAL, bool SPLITP, bool KMASK, int VAR, typename OT>
 __global__ __launch_bounds__(NTHREADS, 2) void fa3_fwd_kernel(const FwdParams p) {
     using E = Elem<T>;
     using v8 = typename E::v8;
     using v4 = typename E::v4;
+    typedef __attribute__((address_space(3))) v8 lds_v8;
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
     constexpr int KS = D / 16;                // k-steps of the QK^T product
     constexpr int DB = D / 32;                // 32-wide d blocks of the PV product
     constexpr int CPR = D / 8;                // 16-byte chunks per key row
     constexpr int TILE_BYTES = BLOCK_N * D * 2;
+    constexpr int BUF_BYTES = 2 * TILE_BYTES; // K image + V image
+    constexpr int HALF_TILE = TILE_BYTES / 2; // 32 keys
     constexpr int CHUNKS_PER_THREAD = (BLOCK_N * CPR) / NTHREADS;  // 2 (D=128) or 1 (D=64)
     static_assert(CHUNKS_PER_THREAD >= 1, "tile too small for 512 threads");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // [buf][K|V][TILE_BYTES]
-    lds_char* const smem_l = (lds_char*)smem;
+    lds_char* const smem_l = (lds_char*)smem;   // [buf][K|V][TILE_BYTES]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -155,7 +175,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void fa3_fwd_kernel(const FwdParams p)
     const T* __restrict__ qp = (const T*)p.q + (int64_t)b * p.q_sb + (int64_t)hh * p.q_sh;
     const T* __restrict__ kp = (const T*)p.k + (int64_t)b * p.k_sb + (int64_t)hh * p.k_sh;
     const T* __restrict__ vp = (const T*)p.v + (int64_t)b * p.v_sb + (int64_t)hh * p.v_sh;
-    const uint8_t* __restrict__ kmp = p.key_mask ? p.key_mask + (int64_t)b * p.km_sb : nullptr;
+    const uint8_t* __restrict__ kmp = KMASK ? p.key_mask + (int64_t)b * p.km_sb : nullptr;
 
     // ---- Q fragments: B operand of S^T = K Q^T, lane (r,h) holds Q[my_q][16 ks + 8 h .. +7] -----------
     v8 qf[KS];
@@ -169,154 +189,247 @@ __global__ __launch_bounds__(NTHREADS, 2) void fa3_fwd_kernel(const FwdParams p)
     // ---- K/V staging: thread t moves chunk(s) t, t+512 of the [64][D] tile -------------------------------
     u32x4 kreg[CHUNKS_PER_THREAD], vreg[CHUNKS_PER_THREAD];
     uint32_t st_off[CHUNKS_PER_THREAD];   // LDS byte offset inside a tile image
+    const T* kld[CHUNKS_PER_THREAD];
+    const T* vld[CHUNKS_PER_THREAD];
     int st_key[CHUNKS_PER_THREAD];
-    int st_col[CHUNKS_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < CHUNKS_PER_THREAD; ++i) {
         const int c = tid + i * NTHREADS;
         st_key[i] = c / CPR;
-        st_col[i] = (c % CPR) * 8;
         st_off[i] = tile_off<D>(st_key[i], c % CPR);
+        kld[i] = kp + (c % CPR) * 8;
+        vld[i] = vp + (c % CPR) * 8;
     }
     auto load_tile = [&](int j) {
 #pragma unroll
         for (int i = 0; i < CHUNKS_PER_THREAD; ++i) {
             const int key = min(j * BLOCK_N + st_key[i], p.Sk - 1);
-            kreg[i] = *(const u32x4*)(kp + (int64_t)key * p.k_ss + st_col[i]);
-            vreg[i] = *(const u32x4*)(vp + (int64_t)key * p.v_ss + st_col[i]);
+            kreg[i] = *(const u32x4*)(kld[i] + (int64_t)key * p.k_ss);
+            vreg[i] = *(const u32x4*)(vld[i] + (int64_t)key * p.v_ss);
         }
     };
-    auto store_tile = [&](int buf) {
-        lds_char* kb_ = smem_l + buf * 2 * TILE_BYTES;
-        lds_char* vb_ = kb_ + TILE_BYTES;
+    auto store_tile = [&](auto bufc) {
+        constexpr int BUF = decltype(bufc)::value;
 #pragma unroll
         for (int i = 0; i < CHUNKS_PER_THREAD; ++i) {
-            *(__attribute__((address_space(3))) u32x4*)(kb_ + st_off[i]) = kreg[i];
-            *(__attribute__((address_space(3))) u32x4*)(vb_ + st_off[i]) = vreg[i];
+            *(lds_u32x4*)(smem_l + st_off[i] + BUF * BUF_BYTES) = kreg[i];
+            *(lds_u32x4*)(smem_l + st_off[i] + BUF * BUF_BYTES + TILE_BYTES) = vreg[i];
         }
     };
 
-    // ---- per-lane LDS read offsets (inside a tile image) ---------------------------------------------------
-    // K row read for key block kb, k-step ks: key = 32 kb + r, chunk = 2 ks + h
-    // V transposed read for (kb, s2, dblk, half): lane 4q+p of a 16-lane group gives row q, columns 4p..4p+3
+    // ---- LDS-DMA staging (VAR_GLDS): one wave-instruction moves 64 x 16 B = 1 KiB into LINEAR LDS, so the
+    // XOR swizzle is applied to the per-lane SOURCE chunk (guide rule 21).  Wave w issues pieces w, w+8, ...
+    // piece i covers LDS rows 4i..4i+3 (256 B each); lane l -> row 4i + (l>>4), stored chunk l&15.
+    constexpr int PIECES = TILE_BYTES / 1024;            // 16 (D=128) or 8 (D=64)
+    constexpr int PPW = PIECES / 8;                      // pieces per wave: 2 or 1
+    typedef __attribute__((address_space(1))) const char gchar;
+    int dma_key[PPW];
+    int dma_col;                                         // element offset of the source chunk in its key row
+    {
+        const int R0 = 4 * wave + (lane >> 4);           // LDS row of piece `wave`
+        const int sw = ((R0 & 3) << 2) | ((R0 >> 2) & 3);   // rows 32 apart share the swizzle term
+        const int cc = (lane & 15) ^ sw;                 // logical chunk stored at this lane's position
+        if constexpr (D == 128) {
+            dma_col = cc * 8;
+#pragma unroll
+            for (int t = 0; t < PPW; ++t) dma_key[t] = R0 + 32 * t;
+        } else {
+            dma_col = (cc & 7) * 8;
+#pragma unroll
+            for (int t = 0; t < PPW; ++t) dma_key[t] = 2 * (R0 + 32 * t) + (cc >> 3);
+        }
+    }
+    auto dma_tile = [&](auto bufc, int j) {
+        constexpr int BUF = decltype(bufc)::value;
+#pragma unroll
+        for (int t = 0; t < PPW; ++t) {
+            const int key = min(j * BLOCK_N + dma_key[t], p.Sk - 1);
+            lds_char* kd = smem_l + BUF * BUF_BYTES + (wave + 8 * t) * 1024;
+            __builtin_amdgcn_global_load_lds((gchar*)(kp + (int64_t)key * p.k_ss + dma_col), kd, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gchar*)(vp + (int64_t)key * p.v_ss + dma_col), kd + TILE_BYTES, 16, 0, 0);
+        }
+    };
+
+    // ---- per-lane LDS read offsets, loop invariant; (buffer, key block, k-step) become immediates ----------
+    // K row read (kb, ks): key = 32 kb + r, chunk 2 ks + h.   +32 keys leaves the swizzle term unchanged.
+    uint32_t koff[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = tile_off<D>(r, 2 * ks + h);
+    // V transposed read (kb, s2, db, hi8): lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of the
+    // 4-key x 16-d block at key0 = 32 kb + 16 s2 + 4 h (+8), d0 = 32 db + 16 ((lane>>4)&1)
     const int g1 = (lane >> 4) & 1;
     const int tq = (lane & 15) >> 2;
     const int tp = lane & 3;
+    constexpr int NS2 = (D == 128) ? 1 : 2;   // D=64: two keys per LDS row, the swizzle term depends on s2
+    uint32_t voff[NS2][DB][2];
+#pragma unroll
+    for (int s2 = 0; s2 < NS2; ++s2)
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi)
+                voff[s2][db][hi] = tile_off<D>(16 * s2 + 4 * h + tq + 8 * hi, db * 4 + 2 * g1 + (tp >> 1)) + 8 * (tp & 1);
 
     f32x16 o[DB];
 #pragma unroll
     for (int i = 0; i < DB; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
-    float m_run = -1e30f;   // running row max, raw score units
+    float m_run = -1e30f;   // reference max of the exponentials, raw score units
     float l_run = 0.f;      // this lane's share of the row sum
     const float c = p.scale_log2;
+    const float thr = (VAR & VAR_DEFER_MAX) ? 8.0f / c : 0.0f;   // raw-score headroom before a rescale
 
-    if (nt > 0) {
-        load_tile(0);
-        store_tile(0);
-    }
-    __syncthreads();
+    // ---- one K/V tile: S^T = K Q^T, online softmax, O^T += V^T P^T -------------------------------------------
+    auto compute_tile = [&](auto bufc, int key_base) {
+        constexpr int BUF = decltype(bufc)::value;
+        const lds_char* kimg = smem_l + BUF * BUF_BYTES;
+        const lds_char* vimg = kimg + TILE_BYTES;
 
-    for (int j = 0; j < nt; ++j) {
-        const int cur = j & 1;
-        if (j + 1 < nt) load_tile(j + 1);   // HBM latency hides under this tile's math
-
-        const int key_base = j * BLOCK_N;
-        if (key_base < wave_kv_end) {       // wave-uniform: causal tiles right of this wave's rows are skipped
-            const lds_char* kimg = smem_l + cur * 2 * TILE_BYTES;
-            const lds_char* vimg = kimg + TILE_BYTES;
-
-            // ---- S^T = K Q^T : two 32-key blocks ---------------------------------------------------------
-            f32x16 s[2];
+        // S^T = K Q^T: 16 MFMAs (2 key blocks x KS k-steps), A fragments prefetched PF deep from LDS so the
+        // ds_read latency hides behind the MFMAs already issued (hipcc otherwise emits read -> wait -> mfma)
+        f32x16 s[2];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+            for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+        constexpr int NQK = 2 * KS;
+        constexpr int PF = 4;
+        v8 afr[PF];
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const v8 a = *(const __attribute__((address_space(3))) v8*)(kimg + tile_off<D>(32 * kb + r, 2 * ks + h));
-                    s[kb] = E::mfma(a, qf[ks], s[kb]);
-                }
+        for (int i = 0; i < PF; ++i) afr[i] = *(const lds_v8*)(kimg + koff[i % KS] + (i / KS) * HALF_TILE);
+        if (VAR & VAR_SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < NQK; ++i) {
+            s[i / KS] = E::mfma(afr[i % PF], qf[i % KS], s[i / KS]);
+            if (i + PF < NQK) afr[i % PF] = *(const lds_v8*)(kimg + koff[(i + PF) % KS] + ((i + PF) / KS) * HALF_TILE);
+        }
+        if (VAR & VAR_SETPRIO) __builtin_amdgcn_s_setprio(0);
+        if (VAR & VAR_SCHED) {
+            __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+            for (int i = 0; i < NQK - PF; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
+            __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
+        }
 
-            // ---- mask (tile-uniform test; only diagonal / tail / key-mask tiles pay) -------------------
-            const bool need_mask = (key_base + BLOCK_N > kv_len) || (CAUSAL && key_base + BLOCK_N - 1 > wave_q0) ||
-                                   (kmp != nullptr);
-            if (need_mask) {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int key = key_base + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
-                        bool ok = key < kv_len;
-                        if (CAUSAL) ok = ok && (key <= my_q);
-                        if (kmp) ok = ok && (kmp[min(key, p.Sk - 1)] != 0);
-                        s[kb][e] = ok ? s[kb][e] : -INFINITY;
-                    }
-            }
-
-            // ---- online softmax (flash_attention_3.py:239-246), row = (lane, lane^32) ------------------
-            float mx = s[0][0];
-#pragma unroll
-            for (int e = 1; e < 16; ++e) mx = fmaxf(mx, s[0][e]);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[1][e]);
-            mx = row_pair_max(mx);
-            const float m_new = fmaxf(m_run, mx);
-            const float mc = m_new * c;
-            const float alpha = fast_exp2(m_run * c - mc);
-            m_run = m_new;
-            float psum = 0.f;
+        // mask: wave-uniform test, only diagonal / tail / key-mask tiles pay
+        const bool need_mask = (key_base + BLOCK_N > kv_len) || (CAUSAL && key_base + BLOCK_N - 1 > wave_q0) || KMASK;
+        if (need_mask) {
+            asm volatile("" ::: "memory");   // keep this a real (wave-uniform) branch: hipcc otherwise if-converts
+                                             // it into 32 v_cmp + 32 v_cndmask on EVERY tile
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float pe = fast_exp2(__builtin_fmaf(s[kb][e], c, -mc));
-                    s[kb][e] = pe;
-                    psum += pe;
-                }
-            l_run = l_run * alpha + psum;
-            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // wave-uniform: skip when no row max moved
-#pragma unroll
-                for (int i = 0; i < DB; ++i)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
-            }
-
-            // ---- O^T += V^T P^T ---------------------------------------------------------------------------
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    v8 ph, pl;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float pv = s[kb][8 * s2 + e];
-                        const T hi = (T)pv;
-                        ph[e] = hi;
-                        if (SPLITP) pl[e] = (T)(pv - (float)hi);
-                    }
-                    const int key0 = 32 * kb + 16 * s2 + 4 * h + tq;
-#pragma unroll
-                    for (int db = 0; db < DB; ++db) {
-                        const uint32_t ch = db * 4 + 2 * g1 + (tp >> 1);
-                        const v4 lo = E::tr_read(vimg + tile_off<D>(key0, ch) + 8 * (tp & 1));
-                        const v4 hi4 = E::tr_read(vimg + tile_off<D>(key0 + 8, ch) + 8 * (tp & 1));
-                        v8 a;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            a[e] = lo[e];
-                            a[4 + e] = hi4[e];
-                        }
-                        o[db] = E::mfma(a, ph, o[db]);
-                        if (SPLITP) o[db] = E::mfma(a, pl, o[db]);
-                    }
+                    const int key = key_base + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    bool ok = key < kv_len;
+                    if (CAUSAL) ok = ok && (key <= my_q);
+                    if (KMASK) ok = ok && (kmp[min(key, p.Sk - 1)] != 0);
+                    s[kb][e] = ok ? s[kb][e] : -INFINITY;
                 }
         }
 
-        if (j + 1 < nt) store_tile(cur ^ 1);
-        __syncthreads();
+        // online softmax (flash_attention_3.py:239-246); a row lives in lanes (l, l^32)
+        float mx = max3(s[0][0], s[1][0], s[0][1]);
+        mx = max3(mx, s[1][1], s[0][2]);
+#pragma unroll
+        for (int e = 2; e < 16; e += 2) {
+            mx = max3(mx, s[1][e], s[0][e + 1]);
+            if (e + 2 < 16) mx = max3(mx, s[1][e + 1], s[0][e + 2]);
+            else mx = fmaxf(mx, s[1][e + 1]);
+        }
+        mx = row_pair_max(mx);
+        // rescale only when some row's max outgrew the headroom (thr = 0: whenever any max moved -> exact
+        // lazy rescale; thr > 0: exponentials may reach 2^8, harmless in fp32/bf16 and cancelled by l)
+        if (__builtin_amdgcn_ballot_w64(mx > m_run + thr) != 0) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = fast_exp2((m_run - m_new) * c);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < DB; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+        }
+        const float mc = m_run * c;
+        float psum0 = 0.f, psum1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            s[0][e] = fast_exp2(__builtin_fmaf(s[0][e], c, -mc));
+            s[1][e] = fast_exp2(__builtin_fmaf(s[1][e], c, -mc));
+            psum0 += s[0][e];
+            psum1 += s[1][e];
+        }
+        l_run += psum0 + psum1;
+
+        // O^T += V^T P^T
+        if (VAR & VAR_SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                v8 ph, pl;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pv = s[kb][8 * s2 + e];
+                    const T hi = (T)pv;
+                    ph[e] = hi;
+                    if (SPLITP) pl[e] = (T)(pv - (float)hi);
+                }
+                constexpr int S2I = (D == 128) ? 0 : 1;
+                const int koffs = kb * HALF_TILE + ((D == 128) ? s2 * 16 * 256 : 0);
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const v4 lo = E::tr_read(vimg + voff[s2 * S2I][db][0] + koffs);
+                    const v4 hi4 = E::tr_read(vimg + voff[s2 * S2I][db][1] + koffs);
+                    v8 a;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a[e] = lo[e];
+                        a[4 + e] = hi4[e];
+                    }
+                    o[db] = E::mfma(a, ph, o[db]);
+                    if (SPLITP) o[db] = E::mfma(a, pl, o[db]);
+                }
+            }
+        if (VAR & VAR_SETPRIO) __builtin_amdgcn_s_setprio(0);
+    };
+
+    auto step = [&](auto bufc, int j) {
+        constexpr int BUF = decltype(bufc)::value;
+        if constexpr (VAR & VAR_GLDS) {
+            if (j + 1 < nt) dma_tile(IC<BUF ^ 1>{}, j + 1);   // lands in the other buffer under this tile's math
+            if (j * BLOCK_N < wave_kv_end) compute_tile(bufc, j * BLOCK_N);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed ...
+            __syncthreads();                                  // ... and so have everybody else's
+        } else {
+            if (j + 1 < nt) load_tile(j + 1);              // HBM latency hides under this tile's math
+            if (j * BLOCK_N < wave_kv_end) compute_tile(bufc, j * BLOCK_N);   // wave-uniform causal skip
+            if (j + 1 < nt) store_tile(IC<BUF ^ 1>{});
+            __syncthreads();
+        }
+    };
+
+    if (nt > 0) {
+        if constexpr (VAR & VAR_GLDS) {
+            dma_tile(IC<0>{}, 0);
+        } else {
+            load_tile(0);
+            store_tile(IC<0>{});
+        }
+    }
+    // Q must have LANDED before the loop: hipcc's waitcnt pass otherwise keeps vmcnt(7..0) waits for the Q
+    // loads inside the loop body, where they drain the K/V prefetch of the next tile on every iteration.
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int j = 0; j < nt; j += 2) {
+        step(IC<0>{}, j);
+        if (j + 1 < nt) step(IC<1>{}, j + 1);
     }
 
     // ---- epilogue: normalise (flash_attention_3.py:250 does it per tile; once is equivalent) ------------

@@ -16,37 +16,67 @@ thread_local int g_last_hip_error = 0;
 
 struct Variant {
     const void* fn;
-    const char* name;
+    char name[96];
     int lds_bytes;
 };
 
-template <typename T, int D, bool C, bool S, typename OT>
-Variant make_variant(const char* name) {
-    return Variant{(const void*)&pfa::fa3_fwd_kernel<T, D, C, S, OT>, name, 2 * 2 * pfa::BLOCK_N * D * 2};
+template <typename T, int D, bool C, bool S, bool K, int VAR, typename OT>
+Variant mk(const char* tn, const char* on) {
+    Variant v;
+    v.fn = (const void*)&pfa::fa3_fwd_kernel<T, D, C, S, K, VAR, OT>;
+    snprintf(v.name, sizeof(v.name), "fa3_fwd_%s_d%d_%s%s%s_%s_v%d", tn, D, C ? "causal" : "full", S ? "_splitp" : "",
+             K ? "_kmask" : "", on, VAR);
+    v.lds_bytes = 2 * 2 * pfa::BLOCK_N * D * 2;
+    return v;
 }
 
-#define PFA_V(T, TN, D, C, S, OT, ON) make_variant<T, D, C, S, OT>("fa3_fwd_" TN "_d" #D "_" #C "_" #S "_" ON)
+// Production variants: every (dtype, D, causal, split, kmask, out) at VAR_DEFAULT.
+template <typename T, int D, bool C, bool S, bool K>
+Variant by_out(bool out32, const char* tn) {
+    return out32 ? mk<T, D, C, S, K, pfa::VAR_DEFAULT, float>(tn, "o32") : mk<T, D, C, S, K, pfa::VAR_DEFAULT, T>(tn, "o16");
+}
+template <typename T, int D, bool C, bool S>
+Variant by_kmask(bool kmask, bool out32, const char* tn) {
+    return kmask ? by_out<T, D, C, S, true>(out32, tn) : by_out<T, D, C, S, false>(out32, tn);
+}
+template <typename T, int D, bool C>
+Variant by_split(bool split, bool kmask, bool out32, const char* tn) {
+    return split ? by_kmask<T, D, C, true>(kmask, out32, tn) : by_kmask<T, D, C, false>(kmask, out32, tn);
+}
+template <typename T, int D>
+Variant by_causal(bool causal, bool split, bool kmask, bool out32, const char* tn) {
+    return causal ? by_split<T, D, true>(split, kmask, out32, tn) : by_split<T, D, false>(split, kmask, out32, tn);
+}
+template <typename T>
+Variant by_d(int D, bool causal, bool split, bool kmask, bool out32, const char* tn) {
+    return D == 128 ? by_causal<T, 128>(causal, split, kmask, out32, tn) : by_causal<T, 64>(causal, split, kmask, out32, tn);
+}
 
-// index: [dtype_in][D==128][causal][split][out_fp32]
-const Variant& pick(int dtype_in, int D, int causal, int split, int out32) {
-    static const Variant tbl[2][2][2][2][2] = {
-        {{{{PFA_V(__bf16, "bf16", 64, false, false, __bf16, "o16"), PFA_V(__bf16, "bf16", 64, false, false, float, "o32")},
-           {PFA_V(__bf16, "bf16", 64, false, true, __bf16, "o16"), PFA_V(__bf16, "bf16", 64, false, true, float, "o32")}},
-          {{PFA_V(__bf16, "bf16", 64, true, false, __bf16, "o16"), PFA_V(__bf16, "bf16", 64, true, false, float, "o32")},
-           {PFA_V(__bf16, "bf16", 64, true, true, __bf16, "o16"), PFA_V(__bf16, "bf16", 64, true, true, float, "o32")}}},
-         {{{PFA_V(__bf16, "bf16", 128, false, false, __bf16, "o16"), PFA_V(__bf16, "bf16", 128, false, false, float, "o32")},
-           {PFA_V(__bf16, "bf16", 128, false, true, __bf16, "o16"), PFA_V(__bf16, "bf16", 128, false, true, float, "o32")}},
-          {{PFA_V(__bf16, "bf16", 128, true, false, __bf16, "o16"), PFA_V(__bf16, "bf16", 128, true, false, float, "o32")},
-           {PFA_V(__bf16, "bf16", 128, true, true, __bf16, "o16"), PFA_V(__bf16, "bf16", 128, true, true, float, "o32")}}}},
-        {{{{PFA_V(_Float16, "fp16", 64, false, false, _Float16, "o16"), PFA_V(_Float16, "fp16", 64, false, false, float, "o32")},
-           {PFA_V(_Float16, "fp16", 64, false, true, _Float16, "o16"), PFA_V(_Float16, "fp16", 64, false, true, float, "o32")}},
-          {{PFA_V(_Float16, "fp16", 64, true, false, _Float16, "o16"), PFA_V(_Float16, "fp16", 64, true, false, float, "o32")},
-           {PFA_V(_Float16, "fp16", 64, true, true, _Float16, "o16"), PFA_V(_Float16, "fp16", 64, true, true, float, "o32")}}},
-         {{{PFA_V(_Float16, "fp16", 128, false, false, _Float16, "o16"), PFA_V(_Float16, "fp16", 128, false, false, float, "o32")},
-           {PFA_V(_Float16, "fp16", 128, false, true, _Float16, "o16"), PFA_V(_Float16, "fp16", 128, false, true, float, "o32")}},
-          {{PFA_V(_Float16, "fp16", 128, true, false, _Float16, "o16"), PFA_V(_Float16, "fp16", 128, true, false, float, "o32")},
-           {PFA_V(_Float16, "fp16", 128, true, true, _Float16, "o16"), PFA_V(_Float16, "fp16", 128, true, true, float, "o32")}}}}};
-    return tbl[dtype_in][D == 128][causal ? 1 : 0][split ? 1 : 0][out32 ? 1 : 0];
+// Experimental variants (A/B only): bf16, D=128, single-P, bf16 store; selected by flags bits 8..15.
+template <int VAR>
+Variant exp_variant(bool causal) {
+    return causal ? mk<__bf16, 128, true, false, false, VAR, __bf16>("bf16", "o16")
+                  : mk<__bf16, 128, false, false, false, VAR, __bf16>("bf16", "o16");
+}
+
+Variant pick(const pfa_fa3_args* a) {
+    const bool causal = a->causal != 0, split = (a->flags & PFA_FLAG_SPLIT_P) != 0, kmask = a->key_mask != nullptr;
+    const bool out32 = a->dtype_out == PFA_DTYPE_FP32;
+    const unsigned var = (a->flags >> 8) & 0xffu;   // 0 = production default
+    if (var != 0 && a->dtype_in == PFA_DTYPE_BF16 && a->D == 128 && !split && !kmask && !out32) {
+        switch (var) {
+            case 1: return exp_variant<0>(causal);                                     // exact lazy rescale
+            case 2: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_SETPRIO>(causal);
+            case 3: return exp_variant<pfa::VAR_SETPRIO>(causal);
+            case 4: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_SCHED>(causal);
+            case 5: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_SCHED | pfa::VAR_SETPRIO>(causal);
+            case 6: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_SCHED | pfa::VAR_GLDS>(causal);
+            case 7: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_GLDS>(causal);
+            default: break;
+        }
+    }
+    return a->dtype_in == PFA_DTYPE_BF16 ? by_d<__bf16>(a->D, causal, split, kmask, out32, "bf16")
+                                         : by_d<_Float16>(a->D, causal, split, kmask, out32, "fp16");
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -55,7 +85,7 @@ bool mult8(int64_t s) { return (s % 8) == 0; }
 int check(const pfa_fa3_args* a) {
     if (!a) return PFA_ERR_NULL;
     if (a->size != sizeof(pfa_fa3_args)) return PFA_ERR_STRUCT_SIZE;
-    if (a->flags & ~(PFA_FLAG_SPLIT_P | PFA_FLAG_NO_XCD_MAP)) return PFA_ERR_FLAGS;
+    if (a->flags & ~(PFA_FLAG_SPLIT_P | PFA_FLAG_NO_XCD_MAP | PFA_FLAG_VARIANT_MASK)) return PFA_ERR_FLAGS;
     if (!a->q || !a->k || !a->v || !a->o) return PFA_ERR_NULL;
     if (a->B <= 0 || a->H <= 0 || a->Sq <= 0 || a->Sk <= 0) return PFA_ERR_SHAPE;
     if (a->D != 64 && a->D != 128) return PFA_ERR_HEAD_DIM;
@@ -122,7 +152,7 @@ int pfa_fa3_check(const pfa_fa3_args* a) { return check(a); }
 int pfa_fa3_describe(const pfa_fa3_args* a, char* buf, size_t n) {
     const int st = check(a);
     if (st != PFA_OK) return st;
-    const Variant& v = pick(a->dtype_in, a->D, a->causal, a->flags & PFA_FLAG_SPLIT_P, a->dtype_out == PFA_DTYPE_FP32);
+    const Variant v = pick(a);
     if (buf && n) {
         strncpy(buf, v.name, n - 1);
         buf[n - 1] = 0;
@@ -147,7 +177,7 @@ int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream) {
     p.nqblk = (a->Sq + pfa::BLOCK_M - 1) / pfa::BLOCK_M;
     p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
 
-    const Variant& v = pick(a->dtype_in, a->D, a->causal, a->flags & PFA_FLAG_SPLIT_P, a->dtype_out == PFA_DTYPE_FP32);
+    const Variant v = pick(a);
     const unsigned grid = (unsigned)(p.nqblk * a->B * a->H);
     void* kargs[] = {&p};
     int prev_dev = -1;

@@ -45,7 +45,7 @@ def _bhsd_strides(t: torch.Tensor):
 
 
 def build_args(q, k, v, out, *, causal=False, seqlens_k=None, key_mask=None, softmax_scale=None,
-               lse=None, split_p=False):
+               lse=None, split_p=False, variant=0):
     """Fill a ``pfa_fa3_args`` from ``[B,H,S,D]``-shaped (arbitrarily strided) tensors."""
     B, H, Sq, D = q.shape
     Sk = k.shape[2]
@@ -61,7 +61,7 @@ def build_args(q, k, v, out, *, causal=False, seqlens_k=None, key_mask=None, sof
         raise ValueError("pfa_fa3_fwd needs device tensors (there is no CPU path)")
     qs, ks, vs, os_ = (_bhsd_strides(t) for t in (q, k, v, out))
     a = _capi.make_args(
-        flags=_capi.PFA_FLAG_SPLIT_P if split_p else 0,
+        flags=(_capi.PFA_FLAG_SPLIT_P if split_p else 0) | ((int(variant) & 0xFF) << 8),
         q=q.data_ptr(), k=k.data_ptr(), v=v.data_ptr(), o=out.data_ptr(),
         q_stride_b=qs[0], q_stride_h=qs[1], q_stride_s=qs[2],
         k_stride_b=ks[0], k_stride_h=ks[1], k_stride_s=ks[2],
@@ -98,7 +98,7 @@ def fa3_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: bo
                 seqlens_k=None, key_mask: Optional[torch.Tensor] = None,
                 softmax_scale: Optional[float] = None, out_dtype: Optional[torch.dtype] = None,
                 return_lse: bool = False, split_p: Optional[bool] = None,
-                out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                out: Optional[torch.Tensor] = None, _variant: int = 0) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """softmax(scale * q k^T + mask) v on the MI355X kernel.
 
     q: ``[B,H,Sq,D]``, k/v: ``[B,H,Sk,D]`` (any batch/head/seq strides that are multiples of 8
@@ -116,7 +116,7 @@ def fa3_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: bo
         out = torch.empty((B, Sq, H, D), dtype=odt, device=q.device).permute(0, 2, 1, 3)
     lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device) if return_lse else None
     args, keep = build_args(q, k, v, out, causal=causal, seqlens_k=seqlens_k, key_mask=key_mask,
-                            softmax_scale=softmax_scale, lse=lse, split_p=split_p)
+                            softmax_scale=softmax_scale, lse=lse, split_p=split_p, variant=_variant)
     stream = torch.cuda.current_stream(q.device).cuda_stream
     st = _capi.load().pfa_fa3_fwd(C.byref(args), C.c_void_p(stream))
     if st in (-3, -4, -5, -6, -7, -10):
