@@ -37,10 +37,9 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 typedef __attribute__((address_space(3))) char lds_char;
 
-constexpr int BLOCK_M = 256;  // Q rows per workgroup
 constexpr int WAVE_M = 32;    // Q rows per wave
 constexpr int BLOCK_N = 64;   // keys per K/V tile
-constexpr int NTHREADS = 512;
+constexpr int block_m(int nw) { return nw * WAVE_M; }   // Q rows per workgroup (nw waves)
 
 struct FwdParams {
     const void* q;
@@ -123,13 +122,32 @@ __device__ __forceinline__ float row_pair_sum(float x) {
 constexpr int VAR_DEFER_MAX = 1;   // T13: rescale O only when a row max grew by > 2^8 (else exact lazy rescale)
 constexpr int VAR_SETPRIO = 2;     // s_setprio(1) around the MFMA clusters
 constexpr int VAR_SCHED = 4;       // pin the QK^T read/MFMA interleave with sched_group_barrier
+constexpr int VAR_NW4 = 16;        // 4-wave workgroups of 128 Q rows, two resident per CU (independent barriers)
 constexpr int VAR_GLDS = 8;        // K/V tiles by LDS-DMA (global_load_lds_dwordx4), swizzle on the source address
-constexpr int VAR_DEFAULT = VAR_DEFER_MAX;
+constexpr int VAR_DEFAULT = VAR_DEFER_MAX | VAR_SCHED | VAR_GLDS;
 
 template <int N> struct IC { static constexpr int value = N; };
 
+// One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses into LDS at lds_dst + 16*lane.
+// Inline asm on purpose: with the builtin, hipcc treats the DMA as a possibly-aliasing LDS store and puts
+// s_waitcnt vmcnt(0) in front of the next ds_read of the OTHER buffer, exposing the whole HBM latency every
+// tile.  Hidden in asm the DMA is invisible to the waitcnt pass; the kernel retires it itself with a counted
+// s_waitcnt vmcnt(N) in front of the barrier that publishes the tile (cdna guide section 5.7 item 1).
+// M0 (LDS base of the DMA) is saved/restored inside the statement; s_nop 0 = the M0-write -> LDS-DMA wait state.
+__device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+
 template <typename T, int D, bool CAUSAL, bool SPLITP, bool KMASK, int VAR, typename OT>
-__global__ __launch_bounds__(NTHREADS, 2) void fa3_fwd_kernel(const FwdParams p) {
+__global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_kernel(const FwdParams p) {
+    constexpr int NW = (VAR & VAR_NW4) ? 4 : 8;
+    constexpr int NTHREADS = NW * 64;
+    constexpr int BLOCK_M = NW * WAVE_M;
     using E = Elem<T>;
     using v8 = typename E::v8;
     using v4 = typename E::v4;
@@ -141,11 +159,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void fa3_fwd_kernel(const FwdParams p)
     constexpr int TILE_BYTES = BLOCK_N * D * 2;
     constexpr int BUF_BYTES = 2 * TILE_BYTES; // K image + V image
     constexpr int HALF_TILE = TILE_BYTES / 2; // 32 keys
-    constexpr int CHUNKS_PER_THREAD = (BLOCK_N * CPR) / NTHREADS;  // 2 (D=128) or 1 (D=64)
-    static_assert(CHUNKS_PER_THREAD >= 1, "tile too small for 512 threads");
+    constexpr int CHUNKS_PER_THREAD = (BLOCK_N * CPR) / NTHREADS;
+    static_assert(CHUNKS_PER_THREAD >= 1, "tile too small for the workgroup");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     lds_char* const smem_l = (lds_char*)smem;   // [buf][K|V][TILE_BYTES]
+    const uint32_t smem_base = (uint32_t)(uintptr_t)smem_l;   // LDS byte address (wave-uniform)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -221,22 +240,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void fa3_fwd_kernel(const FwdParams p)
     // XOR swizzle is applied to the per-lane SOURCE chunk (guide rule 21).  Wave w issues pieces w, w+8, ...
     // piece i covers LDS rows 4i..4i+3 (256 B each); lane l -> row 4i + (l>>4), stored chunk l&15.
     constexpr int PIECES = TILE_BYTES / 1024;            // 16 (D=128) or 8 (D=64)
-    constexpr int PPW = PIECES / 8;                      // pieces per wave: 2 or 1
+    constexpr int PPW = PIECES / NW;                     // pieces per wave
     typedef __attribute__((address_space(1))) const char gchar;
     int dma_key[PPW];
     int dma_col;                                         // element offset of the source chunk in its key row
     {
         const int R0 = 4 * wave + (lane >> 4);           // LDS row of piece `wave`
-        const int sw = ((R0 & 3) << 2) | ((R0 >> 2) & 3);   // rows 32 apart share the swizzle term
+        const int sw = ((R0 & 3) << 2) | ((R0 >> 2) & 3);   // rows 4*NW apart share the swizzle term (NW = 4, 8)
         const int cc = (lane & 15) ^ sw;                 // logical chunk stored at this lane's position
         if constexpr (D == 128) {
             dma_col = cc * 8;
 #pragma unroll
-            for (int t = 0; t < PPW; ++t) dma_key[t] = R0 + 32 * t;
+            for (int t = 0; t < PPW; ++t) dma_key[t] = R0 + 4 * NW * t;
         } else {
             dma_col = (cc & 7) * 8;
 #pragma unroll
-            for (int t = 0; t < PPW; ++t) dma_key[t] = 2 * (R0 + 32 * t) + (cc >> 3);
+            for (int t = 0; t < PPW; ++t) dma_key[t] = 2 * (R0 + 4 * NW * t) + (cc >> 3);
         }
     }
     auto dma_tile = [&](auto bufc, int j) {
@@ -244,9 +263,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void fa3_fwd_kernel(const FwdParams p)
 #pragma unroll
         for (int t = 0; t < PPW; ++t) {
             const int key = min(j * BLOCK_N + dma_key[t], p.Sk - 1);
-            lds_char* kd = smem_l + BUF * BUF_BYTES + (wave + 8 * t) * 1024;
-            __builtin_amdgcn_global_load_lds((gchar*)(kp + (int64_t)key * p.k_ss + dma_col), kd, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gchar*)(vp + (int64_t)key * p.v_ss + dma_col), kd + TILE_BYTES, 16, 0, 0);
+            const uint32_t kd = smem_base + BUF * BUF_BYTES + (wave + NW * t) * 1024;
+            lds_dma16(kp + (int64_t)key * p.k_ss + dma_col, kd);
+            lds_dma16(vp + (int64_t)key * p.v_ss + dma_col, kd + TILE_BYTES);
         }
     };
 
@@ -404,7 +423,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void fa3_fwd_kernel(const FwdParams p)
             if (j + 1 < nt) dma_tile(IC<BUF ^ 1>{}, j + 1);   // lands in the other buffer under this tile's math
             if (j * BLOCK_N < wave_kv_end) compute_tile(bufc, j * BLOCK_N);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed ...
-            __syncthreads();                                  // ... and so have everybody else's
+            __builtin_amdgcn_s_waitcnt(0xC07F);               // (lgkmcnt(0): this wave's LDS reads are done)
+            __builtin_amdgcn_s_barrier();                     // ... and so have everybody else's
         } else {
             if (j + 1 < nt) load_tile(j + 1);              // HBM latency hides under this tile's math
             if (j * BLOCK_N < wave_kv_end) compute_tile(bufc, j * BLOCK_N);   // wave-uniform causal skip

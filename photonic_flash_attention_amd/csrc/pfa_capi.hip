@@ -18,6 +18,8 @@ struct Variant {
     const void* fn;
     char name[96];
     int lds_bytes;
+    int nthreads;
+    int block_m;
 };
 
 template <typename T, int D, bool C, bool S, bool K, int VAR, typename OT>
@@ -27,6 +29,8 @@ Variant mk(const char* tn, const char* on) {
     snprintf(v.name, sizeof(v.name), "fa3_fwd_%s_d%d_%s%s%s_%s_v%d", tn, D, C ? "causal" : "full", S ? "_splitp" : "",
              K ? "_kmask" : "", on, VAR);
     v.lds_bytes = 2 * 2 * pfa::BLOCK_N * D * 2;
+    v.nthreads = ((VAR & pfa::VAR_NW4) ? 4 : 8) * 64;
+    v.block_m = v.nthreads / 2;
     return v;
 }
 
@@ -72,6 +76,8 @@ Variant pick(const pfa_fa3_args* a) {
             case 5: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_SCHED | pfa::VAR_SETPRIO>(causal);
             case 6: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_SCHED | pfa::VAR_GLDS>(causal);
             case 7: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_GLDS>(causal);
+            case 8: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_SCHED | pfa::VAR_GLDS | pfa::VAR_NW4>(causal);
+            case 9: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_GLDS | pfa::VAR_NW4>(causal);
             default: break;
         }
     }
@@ -101,7 +107,7 @@ int check(const pfa_fa3_args* a) {
         if (s % 4 != 0) return PFA_ERR_STRIDE;
     if (!aligned16(a->q) || !aligned16(a->k) || !aligned16(a->v) || !aligned16(a->o)) return PFA_ERR_ALIGN;
     if (a->lse && (reinterpret_cast<uintptr_t>(a->lse) & 3u)) return PFA_ERR_ALIGN;
-    const int64_t nq = (a->Sq + pfa::BLOCK_M - 1) / pfa::BLOCK_M;
+    const int64_t nq = (a->Sq + 127) / 128;
     if (nq * a->B * a->H > 0x7fffffffLL) return PFA_ERR_SHAPE;
     return PFA_OK;
 }
@@ -157,7 +163,7 @@ int pfa_fa3_describe(const pfa_fa3_args* a, char* buf, size_t n) {
         strncpy(buf, v.name, n - 1);
         buf[n - 1] = 0;
     }
-    const int nq = (a->Sq + pfa::BLOCK_M - 1) / pfa::BLOCK_M;
+    const int nq = (a->Sq + v.block_m - 1) / v.block_m;
     return nq * a->B * a->H;
 }
 
@@ -174,10 +180,10 @@ int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream) {
     p.o_sb = a->o_stride_b; p.o_sh = a->o_stride_h; p.o_ss = a->o_stride_s;
     p.km_sb = a->key_mask_stride_b;
     p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
-    p.nqblk = (a->Sq + pfa::BLOCK_M - 1) / pfa::BLOCK_M;
+    const Variant v = pick(a);
+    p.nqblk = (a->Sq + v.block_m - 1) / v.block_m;
     p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
 
-    const Variant v = pick(a);
     const unsigned grid = (unsigned)(p.nqblk * a->B * a->H);
     void* kargs[] = {&p};
     int prev_dev = -1;
@@ -188,7 +194,7 @@ int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream) {
         (void)hipGetLastError();
         return PFA_ERR_DEVICE;
     }
-    e = hipLaunchKernel(v.fn, dim3(grid), dim3(pfa::NTHREADS), kargs, (size_t)v.lds_bytes, (hipStream_t)stream);
+    e = hipLaunchKernel(v.fn, dim3(grid), dim3(v.nthreads), kargs, (size_t)v.lds_bytes, (hipStream_t)stream);
     if (prev_dev != a->device_id) (void)hipSetDevice(prev_dev);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;
