@@ -57,6 +57,7 @@ struct FwdParams {
     int32_t B, H, Sq, Sk;
     int32_t nqblk;        // ceil(Sq / BLOCK_M)
     float scale_log2;     // softmax_scale * log2(e)
+    unsigned long long* dbg;   // VAR_STAMP only: [workgroup][wave][8] cycle sums
 };
 
 template <typename T> struct Elem;
@@ -122,11 +123,37 @@ __device__ __forceinline__ float row_pair_sum(float x) {
 constexpr int VAR_DEFER_MAX = 1;   // T13: rescale O only when a row max grew by > 2^8 (else exact lazy rescale)
 constexpr int VAR_SETPRIO = 2;     // s_setprio(1) around the MFMA clusters
 constexpr int VAR_SCHED = 4;       // pin the QK^T read/MFMA interleave with sched_group_barrier
+constexpr int VAR_STAMP = 512;     // DIAGNOSTIC build: s_memtime phase stamps into FwdParams.dbg (never quote its run time)
+constexpr int VAR_STAGE2 = 256;    // two 64-key tiles per barrier (128 KiB of LDS): half the barriers, waves drift further apart
+constexpr int VAR_LSUM = 128;      // row sums on the matrix pipe: one extra MFMA per k-step against an all-ones A operand
+constexpr int VAR_BUFDMA = 64;     // LDS-DMA by buffer_load ... lds: SRD rebuilt per tile on the SALU, no per-tile VALU
+constexpr int VAR_PIPE = 32;       // software-pipelined half-tile schedule (fa3_fwd_pipe_kernel.h)
 constexpr int VAR_NW4 = 16;        // 4-wave workgroups of 128 Q rows, two resident per CU (independent barriers)
 constexpr int VAR_GLDS = 8;        // K/V tiles by LDS-DMA (global_load_lds_dwordx4), swizzle on the source address
 constexpr int VAR_DEFAULT = VAR_DEFER_MAX | VAR_SCHED | VAR_GLDS;
 
 template <int N> struct IC { static constexpr int value = N; };
+
+// s_memtime stamp as ONE statement with its own lgkmcnt(0) (cdna guide section 7, in-kernel stamps)
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+typedef __amdgpu_buffer_rsrc_t srd_t;
+
+// LDS-DMA piece through a buffer descriptor: lane address = SRD base + voff, out-of-range lanes (rows past the
+// end of the K/V slab) deliver zeros, so ragged tails need no clamp.  s_nop 4: SGPR-written-by-SALU -> VMEM.
+__device__ __forceinline__ void lds_dma16_buf(srd_t srd, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(srd), "s"(lds_dst)
+        : "memory");
+}
 
 // One LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses into LDS at lds_dst + 16*lane.
 // Inline asm on purpose: with the builtin, hipcc treats the DMA as a possibly-aliasing LDS store and puts
@@ -258,14 +285,37 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
             for (int t = 0; t < PPW; ++t) dma_key[t] = 2 * (R0 + 4 * NW * t) + (cc >> 3);
         }
     }
+    // buffer-descriptor form: per-lane byte offsets are loop invariant, the tile steps the SRD base (SALU only)
+    uint32_t kvoff[PPW], vvoff[PPW];
+#pragma unroll
+    for (int t = 0; t < PPW; ++t) {
+        kvoff[t] = (uint32_t)(dma_key[t] * (int)p.k_ss + dma_col) * 2u;
+        vvoff[t] = (uint32_t)(dma_key[t] * (int)p.v_ss + dma_col) * 2u;
+    }
+    const int64_t k_slab = ((int64_t)(p.Sk - 1) * p.k_ss + D) * 2;   // bytes of this (b,h) K slab
+    const int64_t v_slab = ((int64_t)(p.Sk - 1) * p.v_ss + D) * 2;
     auto dma_tile = [&](auto bufc, int j) {
         constexpr int BUF = decltype(bufc)::value;
+        if constexpr (VAR & VAR_BUFDMA) {
+            const int64_t kstep = (int64_t)j * BLOCK_N * p.k_ss * 2, vstep = (int64_t)j * BLOCK_N * p.v_ss * 2;
+            const srd_t ksrd = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((const char*)kp + kstep), 0, (int)max((int64_t)0, k_slab - kstep), 0x00020000);
+            const srd_t vsrd = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((const char*)vp + vstep), 0, (int)max((int64_t)0, v_slab - vstep), 0x00020000);
 #pragma unroll
-        for (int t = 0; t < PPW; ++t) {
-            const int key = min(j * BLOCK_N + dma_key[t], p.Sk - 1);
-            const uint32_t kd = smem_base + BUF * BUF_BYTES + (wave + NW * t) * 1024;
-            lds_dma16(kp + (int64_t)key * p.k_ss + dma_col, kd);
-            lds_dma16(vp + (int64_t)key * p.v_ss + dma_col, kd + TILE_BYTES);
+            for (int t = 0; t < PPW; ++t) {
+                const uint32_t kd = smem_base + BUF * BUF_BYTES + (wave + NW * t) * 1024;
+                lds_dma16_buf(ksrd, kvoff[t], kd);
+                lds_dma16_buf(vsrd, vvoff[t], kd + TILE_BYTES);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < PPW; ++t) {
+                const int key = min(j * BLOCK_N + dma_key[t], p.Sk - 1);
+                const uint32_t kd = smem_base + BUF * BUF_BYTES + (wave + NW * t) * 1024;
+                lds_dma16(kp + (int64_t)key * p.k_ss + dma_col, kd);
+                lds_dma16(vp + (int64_t)key * p.v_ss + dma_col, kd + TILE_BYTES);
+            }
         }
     };
 
@@ -273,7 +323,7 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
     // K row read (kb, ks): key = 32 kb + r, chunk 2 ks + h.   +32 keys leaves the swizzle term unchanged.
     uint32_t koff[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) koff[ks] = tile_off<D>(r, 2 * ks + h);
+    for (int ks = 0; ks < KS; ++ks) koff[ks] = smem_base + tile_off<D>(r, 2 * ks + h);   // absolute LDS address
     // V transposed read (kb, s2, db, hi8): lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of the
     // 4-key x 16-d block at key0 = 32 kb + 16 s2 + 4 h (+8), d0 = 32 db + 16 ((lane>>4)&1)
     const int g1 = (lane >> 4) & 1;
@@ -287,7 +337,7 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
         for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int hi = 0; hi < 2; ++hi)
-                voff[s2][db][hi] = tile_off<D>(16 * s2 + 4 * h + tq + 8 * hi, db * 4 + 2 * g1 + (tp >> 1)) + 8 * (tp & 1);
+                voff[s2][db][hi] = smem_base + tile_off<D>(16 * s2 + 4 * h + tq + 8 * hi, db * 4 + 2 * g1 + (tp >> 1)) + 8 * (tp & 1);
 
     f32x16 o[DB];
 #pragma unroll
@@ -295,14 +345,21 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
     float m_run = -1e30f;   // reference max of the exponentials, raw score units
-    float l_run = 0.f;      // this lane's share of the row sum
+    float l_run = 0.f;      // this lane's share of the row sum (VALU form)
+    f32x16 lacc;            // VAR_LSUM: every register = the row sum of this lane's query row (matrix-pipe form)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
+    v8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (T)1.0f;
     const float c = p.scale_log2;
     const float thr = (VAR & VAR_DEFER_MAX) ? 8.0f / c : 0.0f;   // raw-score headroom before a rescale
 
+    unsigned long long st_qk_end = 0;
     // ---- one K/V tile: S^T = K Q^T, online softmax, O^T += V^T P^T -------------------------------------------
     auto compute_tile = [&](auto bufc, int key_base) {
         constexpr int BUF = decltype(bufc)::value;
-        const lds_char* kimg = smem_l + BUF * BUF_BYTES;
+        const lds_char* kimg = (const lds_char*)(uintptr_t)(BUF * BUF_BYTES);   // koff[]/voff[] carry the LDS base
         const lds_char* vimg = kimg + TILE_BYTES;
 
         // S^T = K Q^T: 16 MFMAs (2 key blocks x KS k-steps), A fragments prefetched PF deep from LDS so the
@@ -334,6 +391,10 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
             __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
         }
 
+        if constexpr (VAR & VAR_STAMP) {   // QK^T segment: from compute start to the last QK MFMA issued
+            const unsigned long long tq1 = stamp();
+            st_qk_end = tq1;
+        }
         // mask: wave-uniform test, only diagonal / tail / key-mask tiles pay
         const bool need_mask = (key_base + BLOCK_N > kv_len) || (CAUSAL && key_base + BLOCK_N - 1 > wave_q0) || KMASK;
         if (need_mask) {
@@ -368,6 +429,10 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
             const float alpha = fast_exp2((m_run - m_new) * c);
             m_run = m_new;
             l_run *= alpha;
+            if (VAR & VAR_LSUM) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) lacc[e] *= alpha;
+            }
 #pragma unroll
             for (int i = 0; i < DB; ++i)
 #pragma unroll
@@ -379,10 +444,12 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
         for (int e = 0; e < 16; ++e) {
             s[0][e] = fast_exp2(__builtin_fmaf(s[0][e], c, -mc));
             s[1][e] = fast_exp2(__builtin_fmaf(s[1][e], c, -mc));
-            psum0 += s[0][e];
-            psum1 += s[1][e];
+            if (!(VAR & VAR_LSUM)) {
+                psum0 += s[0][e];
+                psum1 += s[1][e];
+            }
         }
-        l_run += psum0 + psum1;
+        if (!(VAR & VAR_LSUM)) l_run += psum0 + psum1;
 
         // O^T += V^T P^T
         if (VAR & VAR_SETPRIO) __builtin_amdgcn_s_setprio(1);
@@ -397,6 +464,10 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
                     const T hi = (T)pv;
                     ph[e] = hi;
                     if (SPLITP) pl[e] = (T)(pv - (float)hi);
+                }
+                if (VAR & VAR_LSUM) {   // l += sum over this k-step's 16 keys of the ROUNDED p (matches the PV numerator)
+                    lacc = E::mfma(ones, ph, lacc);
+                    if (SPLITP) lacc = E::mfma(ones, pl, lacc);
                 }
                 constexpr int S2I = (D == 128) ? 0 : 1;
                 const int koffs = kb * HALF_TILE + ((D == 128) ? s2 * 16 * 256 : 0);
@@ -417,9 +488,24 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
         if (VAR & VAR_SETPRIO) __builtin_amdgcn_s_setprio(0);
     };
 
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // VAR_STAMP: dma issue | compute | vmcnt wait | barrier | tiles
+    unsigned long long st_qk = 0;
     auto step = [&](auto bufc, int j) {
         constexpr int BUF = decltype(bufc)::value;
-        if constexpr (VAR & VAR_GLDS) {
+        if constexpr ((VAR & VAR_GLDS) && (VAR & VAR_STAMP)) {
+            const unsigned long long t0 = stamp();
+            if (j + 1 < nt) dma_tile(IC<BUF ^ 1>{}, j + 1);
+            const unsigned long long t1 = stamp();
+            if (j * BLOCK_N < wave_kv_end) compute_tile(bufc, j * BLOCK_N);
+            const unsigned long long t2 = stamp();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long t3 = stamp();
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+            const unsigned long long t4 = stamp();
+            st_acc[5] += st_qk_end - t1;   // QK^T segment of the compute
+            st_acc[0] += t1 - t0; st_acc[1] += t2 - t1; st_acc[2] += t3 - t2; st_acc[3] += t4 - t3; st_acc[4] += 1;
+        } else if constexpr (VAR & VAR_GLDS) {
             if (j + 1 < nt) dma_tile(IC<BUF ^ 1>{}, j + 1);   // lands in the other buffer under this tile's math
             if (j * BLOCK_N < wave_kv_end) compute_tile(bufc, j * BLOCK_N);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed ...
@@ -436,6 +522,9 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
     if (nt > 0) {
         if constexpr (VAR & VAR_GLDS) {
             dma_tile(IC<0>{}, 0);
+            if constexpr (VAR & VAR_STAGE2) {
+                if (nt > 1) dma_tile(IC<1>{}, 1);
+            }
         } else {
             load_tile(0);
             store_tile(IC<0>{});
@@ -447,13 +536,41 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int j = 0; j < nt; j += 2) {
-        step(IC<0>{}, j);
-        if (j + 1 < nt) step(IC<1>{}, j + 1);
+    if constexpr (VAR & VAR_STAGE2) {
+        // stage = two tiles in LDS slots {2P, 2P+1}; one barrier per stage
+        static_assert((VAR & VAR_GLDS) != 0, "VAR_STAGE2 needs the LDS-DMA path");
+        auto stage = [&](auto pc, int js) {
+            constexpr int P = decltype(pc)::value;
+            const int j0 = 2 * js;
+            if (j0 + 2 < nt) dma_tile(IC<2 * (P ^ 1)>{}, j0 + 2);
+            if (j0 + 3 < nt) dma_tile(IC<2 * (P ^ 1) + 1>{}, j0 + 3);
+            if (j0 * BLOCK_N < wave_kv_end) compute_tile(IC<2 * P>{}, j0 * BLOCK_N);
+            if (j0 + 1 < nt && (j0 + 1) * BLOCK_N < wave_kv_end) compute_tile(IC<2 * P + 1>{}, (j0 + 1) * BLOCK_N);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+        };
+        const int ns = (nt + 1) / 2;
+        for (int js = 0; js < ns; js += 2) {
+            stage(IC<0>{}, js);
+            if (js + 1 < ns) stage(IC<1>{}, js + 1);
+        }
+    } else {
+        for (int j = 0; j < nt; j += 2) {
+            step(IC<0>{}, j);
+            if (j + 1 < nt) step(IC<1>{}, j + 1);
+        }
     }
 
+    if constexpr (VAR & VAR_STAMP) {
+        if (lane == 0 && p.dbg) {
+            unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d[i] = st_acc[i];
+        }
+    }
     // ---- epilogue: normalise (flash_attention_3.py:250 does it per tile; once is equivalent) ------------
-    const float l_tot = row_pair_sum(l_run);
+    const float l_tot = (VAR & VAR_LSUM) ? lacc[0] : row_pair_sum(l_run);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;   // fully masked row -> zeros (documented divergence)
     if (my_q < p.Sq) {
         OT* orow = (OT*)p.o + (int64_t)b * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)my_q * p.o_ss;

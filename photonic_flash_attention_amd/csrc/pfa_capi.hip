@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include "fa3_fwd_kernel.h"
+#include "fa3_fwd_pipe_kernel.h"
 
 namespace {
 
@@ -25,10 +26,11 @@ struct Variant {
 template <typename T, int D, bool C, bool S, bool K, int VAR, typename OT>
 Variant mk(const char* tn, const char* on) {
     Variant v;
-    v.fn = (const void*)&pfa::fa3_fwd_kernel<T, D, C, S, K, VAR, OT>;
+    if constexpr (VAR & pfa::VAR_PIPE) v.fn = (const void*)&pfa::fa3_fwd_pipe_kernel<T, D, C, S, K, VAR, OT>;
+    else v.fn = (const void*)&pfa::fa3_fwd_kernel<T, D, C, S, K, VAR, OT>;
     snprintf(v.name, sizeof(v.name), "fa3_fwd_%s_d%d_%s%s%s_%s_v%d", tn, D, C ? "causal" : "full", S ? "_splitp" : "",
              K ? "_kmask" : "", on, VAR);
-    v.lds_bytes = 2 * 2 * pfa::BLOCK_N * D * 2;
+    v.lds_bytes = ((VAR & pfa::VAR_STAGE2) ? 4 : 2) * 2 * pfa::BLOCK_N * D * 2;
     v.nthreads = ((VAR & pfa::VAR_NW4) ? 4 : 8) * 64;
     v.block_m = v.nthreads / 2;
     return v;
@@ -78,6 +80,13 @@ Variant pick(const pfa_fa3_args* a) {
             case 7: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_GLDS>(causal);
             case 8: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_SCHED | pfa::VAR_GLDS | pfa::VAR_NW4>(causal);
             case 9: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_GLDS | pfa::VAR_NW4>(causal);
+            case 12: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_BUFDMA>(causal);
+            case 13: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_LSUM>(causal);
+            case 14: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_BUFDMA | pfa::VAR_LSUM>(causal);
+            case 15: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_BUFDMA | pfa::VAR_STAGE2>(causal);
+            case 16: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_BUFDMA | pfa::VAR_STAMP>(causal);
+            case 10: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_PIPE>(causal);
+            case 11: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_PIPE | pfa::VAR_SCHED>(causal);
             default: break;
         }
     }
@@ -180,6 +189,7 @@ int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream) {
     p.o_sb = a->o_stride_b; p.o_sh = a->o_stride_h; p.o_ss = a->o_stride_s;
     p.km_sb = a->key_mask_stride_b;
     p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
+    p.dbg = (unsigned long long*)a->workspace;   // only the diagnostic VAR_STAMP variant writes it
     const Variant v = pick(a);
     p.nqblk = (a->Sq + v.block_m - 1) / v.block_m;
     p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
@@ -194,6 +204,8 @@ int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream) {
         (void)hipGetLastError();
         return PFA_ERR_DEVICE;
     }
+    if (v.lds_bytes > 64 * 1024)   // opt in to > 64 KiB of dynamic LDS (idempotent, per function)
+        (void)hipFuncSetAttribute(v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds_bytes);
     e = hipLaunchKernel(v.fn, dim3(grid), dim3(v.nthreads), kargs, (size_t)v.lds_bytes, (hipStream_t)stream);
     if (prev_dev != a->device_id) (void)hipSetDevice(prev_dev);
     if (e != hipSuccess) {

@@ -14,6 +14,7 @@ No fallback lives here: unsupported arguments raise ``ValueError`` (pre-launch
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -98,7 +99,7 @@ def fa3_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: bo
                 seqlens_k=None, key_mask: Optional[torch.Tensor] = None,
                 softmax_scale: Optional[float] = None, out_dtype: Optional[torch.dtype] = None,
                 return_lse: bool = False, split_p: Optional[bool] = None,
-                out: Optional[torch.Tensor] = None, _variant: int = 0) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+                out: Optional[torch.Tensor] = None, _variant: Optional[int] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """softmax(scale * q k^T + mask) v on the MI355X kernel.
 
     q: ``[B,H,Sq,D]``, k/v: ``[B,H,Sk,D]`` (any batch/head/seq strides that are multiples of 8
@@ -109,6 +110,8 @@ def fa3_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: bo
     fp32 reference ("numerics").
     """
     B, H, Sq, D = q.shape
+    if _variant is None:   # development only: experimental kernel variant (include/pfa_hip.h PFA_FLAG_VARIANT_MASK)
+        _variant = int(os.environ.get("PFA_VARIANT", "0"))
     odt = q.dtype if out_dtype is None else out_dtype
     if split_p is None:
         split_p = odt == torch.float32
