@@ -99,8 +99,10 @@ def parity_check(q, k, v, causal, heads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    # defaults: long enough to sit past the clock/power transient of a freshly started process (the first ~60
+    # launches run 10-25 % slower than steady state on MI355X: profiles/r01_v2_C3_rocprof_summary.md)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=300)
     ap.add_argument("--workload", default="C3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")

@@ -123,6 +123,9 @@ __device__ __forceinline__ float row_pair_sum(float x) {
 constexpr int VAR_DEFER_MAX = 1;   // T13: rescale O only when a row max grew by > 2^8 (else exact lazy rescale)
 constexpr int VAR_SETPRIO = 2;     // s_setprio(1) around the MFMA clusters
 constexpr int VAR_SCHED = 4;       // pin the QK^T read/MFMA interleave with sched_group_barrier
+constexpr int VAR_YPRIO = 2048;    // static s_setprio 1 for the younger wave half (waves NW/2..NW-1)
+constexpr int VAR_LATEDMA = 4096;  // waves NW/2.. issue their DMA pieces after QK^T instead of at the top of the tile
+constexpr int VAR_STAGGER = 1024;  // waves 4-7 one phase behind waves 0-3 (fa3_fwd_stagger_kernel.h)
 constexpr int VAR_STAMP = 512;     // DIAGNOSTIC build: s_memtime phase stamps into FwdParams.dbg (never quote its run time)
 constexpr int VAR_STAGE2 = 256;    // two 64-key tiles per barrier (128 KiB of LDS): half the barriers, waves drift further apart
 constexpr int VAR_LSUM = 128;      // row sums on the matrix pipe: one extra MFMA per k-step against an all-ones A operand
@@ -130,7 +133,7 @@ constexpr int VAR_BUFDMA = 64;     // LDS-DMA by buffer_load ... lds: SRD rebuil
 constexpr int VAR_PIPE = 32;       // software-pipelined half-tile schedule (fa3_fwd_pipe_kernel.h)
 constexpr int VAR_NW4 = 16;        // 4-wave workgroups of 128 Q rows, two resident per CU (independent barriers)
 constexpr int VAR_GLDS = 8;        // K/V tiles by LDS-DMA (global_load_lds_dwordx4), swizzle on the source address
-constexpr int VAR_DEFAULT = VAR_DEFER_MAX | VAR_SCHED | VAR_GLDS;
+constexpr int VAR_DEFAULT = VAR_DEFER_MAX | VAR_SCHED | VAR_GLDS | VAR_BUFDMA;
 
 template <int N> struct IC { static constexpr int value = N; };
 
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
 
     unsigned long long st_qk_end = 0;
     // ---- one K/V tile: S^T = K Q^T, online softmax, O^T += V^T P^T -------------------------------------------
-    auto compute_tile = [&](auto bufc, int key_base) {
+    auto compute_tile = [&](auto bufc, int key_base, int jnext = -1) {
         constexpr int BUF = decltype(bufc)::value;
         const lds_char* kimg = (const lds_char*)(uintptr_t)(BUF * BUF_BYTES);   // koff[]/voff[] carry the LDS base
         const lds_char* vimg = kimg + TILE_BYTES;
@@ -391,6 +394,9 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
             __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
         }
 
+        if constexpr (VAR & VAR_LATEDMA) {
+            if (jnext >= 0) dma_tile(IC<BUF ^ 1>{}, jnext);   // late issue (younger half): off the post-barrier rush
+        }
         if constexpr (VAR & VAR_STAMP) {   // QK^T segment: from compute start to the last QK MFMA issued
             const unsigned long long tq1 = stamp();
             st_qk_end = tq1;
@@ -505,6 +511,13 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
             const unsigned long long t4 = stamp();
             st_acc[5] += st_qk_end - t1;   // QK^T segment of the compute
             st_acc[0] += t1 - t0; st_acc[1] += t2 - t1; st_acc[2] += t3 - t2; st_acc[3] += t4 - t3; st_acc[4] += 1;
+        } else if constexpr ((VAR & VAR_GLDS) && (VAR & VAR_LATEDMA)) {
+            const bool late = (wave >= NW / 2) && (j * BLOCK_N < wave_kv_end);
+            if (j + 1 < nt && !late) dma_tile(IC<BUF ^ 1>{}, j + 1);
+            if (j * BLOCK_N < wave_kv_end) compute_tile(bufc, j * BLOCK_N, (late && j + 1 < nt) ? j + 1 : -1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
         } else if constexpr (VAR & VAR_GLDS) {
             if (j + 1 < nt) dma_tile(IC<BUF ^ 1>{}, j + 1);   // lands in the other buffer under this tile's math
             if (j * BLOCK_N < wave_kv_end) compute_tile(bufc, j * BLOCK_N);
@@ -529,6 +542,9 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
             load_tile(0);
             store_tile(IC<0>{});
         }
+    }
+    if constexpr (VAR & VAR_YPRIO) {
+        if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);   // wave is an SGPR value: a real scalar branch
     }
     // Q must have LANDED before the loop: hipcc's waitcnt pass otherwise keeps vmcnt(7..0) waits for the Q
     // loads inside the loop body, where they drain the K/V prefetch of the next tile on every iteration.

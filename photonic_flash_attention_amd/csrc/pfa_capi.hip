@@ -10,6 +10,7 @@
 
 #include "fa3_fwd_kernel.h"
 #include "fa3_fwd_pipe_kernel.h"
+#include "fa3_fwd_stagger_kernel.h"
 
 namespace {
 
@@ -26,11 +27,13 @@ struct Variant {
 template <typename T, int D, bool C, bool S, bool K, int VAR, typename OT>
 Variant mk(const char* tn, const char* on) {
     Variant v;
-    if constexpr (VAR & pfa::VAR_PIPE) v.fn = (const void*)&pfa::fa3_fwd_pipe_kernel<T, D, C, S, K, VAR, OT>;
+    if constexpr (VAR & pfa::VAR_STAGGER) v.fn = (const void*)&pfa::fa3_fwd_stagger_kernel<T, D, C, S, K, VAR, OT>;
+    else if constexpr (VAR & pfa::VAR_PIPE) v.fn = (const void*)&pfa::fa3_fwd_pipe_kernel<T, D, C, S, K, VAR, OT>;
     else v.fn = (const void*)&pfa::fa3_fwd_kernel<T, D, C, S, K, VAR, OT>;
     snprintf(v.name, sizeof(v.name), "fa3_fwd_%s_d%d_%s%s%s_%s_v%d", tn, D, C ? "causal" : "full", S ? "_splitp" : "",
              K ? "_kmask" : "", on, VAR);
     v.lds_bytes = ((VAR & pfa::VAR_STAGE2) ? 4 : 2) * 2 * pfa::BLOCK_N * D * 2;
+    if (VAR & pfa::VAR_STAGGER) v.lds_bytes = 5 * pfa::BLOCK_N * D * 2;   // K ring 2 + V ring 3
     v.nthreads = ((VAR & pfa::VAR_NW4) ? 4 : 8) * 64;
     v.block_m = v.nthreads / 2;
     return v;
@@ -71,22 +74,16 @@ Variant pick(const pfa_fa3_args* a) {
     const unsigned var = (a->flags >> 8) & 0xffu;   // 0 = production default
     if (var != 0 && a->dtype_in == PFA_DTYPE_BF16 && a->D == 128 && !split && !kmask && !out32) {
         switch (var) {
-            case 1: return exp_variant<0>(causal);                                     // exact lazy rescale
-            case 2: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_SETPRIO>(causal);
-            case 3: return exp_variant<pfa::VAR_SETPRIO>(causal);
-            case 4: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_SCHED>(causal);
-            case 5: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_SCHED | pfa::VAR_SETPRIO>(causal);
-            case 6: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_SCHED | pfa::VAR_GLDS>(causal);
-            case 7: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_GLDS>(causal);
-            case 8: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_SCHED | pfa::VAR_GLDS | pfa::VAR_NW4>(causal);
-            case 9: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_GLDS | pfa::VAR_NW4>(causal);
-            case 12: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_BUFDMA>(causal);
-            case 13: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_LSUM>(causal);
-            case 14: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_BUFDMA | pfa::VAR_LSUM>(causal);
-            case 15: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_BUFDMA | pfa::VAR_STAGE2>(causal);
-            case 16: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_BUFDMA | pfa::VAR_STAMP>(causal);
-            case 10: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_PIPE>(causal);
-            case 11: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_PIPE | pfa::VAR_SCHED>(causal);
+            case 1: return exp_variant<pfa::VAR_SCHED | pfa::VAR_GLDS | pfa::VAR_BUFDMA>(causal);          // exact lazy rescale (no defer-max)
+            case 2: return exp_variant<pfa::VAR_DEFER_MAX>(causal);                                         // register staging, compiler-ordered QK
+            case 3: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_SCHED>(causal);                        // + pinned QK read/MFMA interleave
+            case 4: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_SCHED | pfa::VAR_GLDS>(causal);        // + LDS-DMA (global_load_lds)
+            case 5: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_LSUM>(causal);                           // row sums on the matrix pipe
+            case 6: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_STAGE2>(causal);                         // two tiles per barrier
+            case 7: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_SCHED | pfa::VAR_GLDS | pfa::VAR_NW4>(causal);   // 2 x 4-wave workgroups per CU
+            case 8: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_PIPE | pfa::VAR_SCHED>(causal);        // half-tile software pipeline
+            case 9: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_STAGGER>(causal);                      // staggered wave halves
+            case 16: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_STAMP>(causal);                         // diagnostic stamps
             default: break;
         }
     }
@@ -118,6 +115,11 @@ int check(const pfa_fa3_args* a) {
     if (a->lse && (reinterpret_cast<uintptr_t>(a->lse) & 3u)) return PFA_ERR_ALIGN;
     const int64_t nq = (a->Sq + 127) / 128;
     if (nq * a->B * a->H > 0x7fffffffLL) return PFA_ERR_SHAPE;
+    // K/V slabs of one (batch, head) are addressed through 32-bit buffer descriptors
+    if (((int64_t)(a->Sk - 1) * a->k_stride_s + a->D) * 2 > 0x7fffffffLL) return PFA_ERR_SHAPE;
+    if (((int64_t)(a->Sk - 1) * a->v_stride_s + a->D) * 2 > 0x7fffffffLL) return PFA_ERR_SHAPE;
+    if (a->k_stride_s < 0 || a->v_stride_s < 0 || a->k_stride_s * 64 > 0x3fffffffLL || a->v_stride_s * 64 > 0x3fffffffLL)
+        return PFA_ERR_STRIDE;
     return PFA_OK;
 }
 
