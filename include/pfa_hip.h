@@ -10,7 +10,9 @@
  *                                     (called from FlashAttention3.forward at :102)
  *   pfa_fa3_args.softmax_scale         the `q = q * self.scaling` pass at :138, folded into the kernel
  *   pfa_fa3_args.causal / seqlens_k /  the `attention_mask` argument (:165-168, :234-236): causal = 4-D
- *     key_mask                         lower-triangular mask, seqlens_k / key_mask = 2-D [B,Sk] key mask
+ *     key_mask / mask                  lower-triangular mask, seqlens_k / key_mask = 2-D [B,Sk] key mask,
+ *                                      mask = any 4-D mask
+ *   pfa_fa3_weights                    the `need_weights=True` outputs (:171,:180,:257-258)
  *   pfa_fa3_args.o strides             the `.transpose(1,2).contiguous()` copy at :107 (the kernel writes
  *                                     [B,S,H,D] directly, so the copy disappears)
  *   pfa_fa3_workspace_bytes           the tile-size memory budget of :264-293 (this path needs none)
@@ -36,7 +38,7 @@
 extern "C" {
 #endif
 
-#define PFA_ABI_VERSION 1
+#define PFA_ABI_VERSION 2
 
 typedef enum pfa_status {
     PFA_OK = 0,
@@ -97,6 +99,13 @@ typedef struct pfa_fa3_args {
 
     void*   workspace;          /* pfa_fa3_workspace_bytes() bytes, may be NULL if 0 */
     size_t  workspace_bytes;
+
+    /* ABI v2: general mask, the reference's 4-D `attention_mask` (flash_attention_3.py:168,235-236).
+     * u8, 0 = masked, element (b,h,i,j) at mask + b*mask_stride_b + h*mask_stride_h + i*mask_stride_q +
+     * j*mask_stride_k (BYTE strides; 0 broadcasts a dimension).  At most one of key_mask / mask may be set;
+     * `causal` and `seqlens_k` combine with either. */
+    const uint8_t* mask;
+    int64_t mask_stride_b, mask_stride_h, mask_stride_q, mask_stride_k;
 } pfa_fa3_args;
 
 /* ABI version of the loaded library (== PFA_ABI_VERSION of the header it was built from). */
@@ -119,6 +128,17 @@ int pfa_fa3_check(const pfa_fa3_args* a);
 
 /* Enqueue the forward on `stream` (hipStream_t as void*, NULL = default stream). */
 int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream);
+
+/*
+ * Attention weights on request (the reference's need_weights=True, flash_attention_3.py:171,180,257-258):
+ * W[b,h,i,j] = exp(scale*<q_i,k_j> + mask - lse[b,h,i]), the TRUE softmax row (the reference's tiled branch
+ * returns un-renormalised tiles; documented divergence).  `a` is the argument block of the forward call that
+ * produced a->lse (required; a->v and a->o are ignored).  W is addressed base + b*w_stride_b + h*w_stride_h +
+ * i*w_stride_q + j (ELEMENT strides, last dim contiguous), dtype w_dtype = a->dtype_in or PFA_DTYPE_FP32.
+ * For causal or seqlens_k problems the caller must zero-fill W first (fully masked 32-key blocks are skipped).
+ */
+int pfa_fa3_weights(const pfa_fa3_args* a, void* w, int32_t w_dtype, int64_t w_stride_b, int64_t w_stride_h,
+                    int64_t w_stride_q, void* stream);
 
 /*
  * Kernel-selection introspection for tests/bench: writes the name of the kernel variant pfa_fa3_fwd

@@ -13,7 +13,7 @@ import os
 import threading
 from typing import Optional
 
-PFA_ABI_VERSION = 1
+PFA_ABI_VERSION = 2
 PFA_DTYPE_BF16, PFA_DTYPE_FP16, PFA_DTYPE_FP32 = 0, 1, 2
 PFA_FLAG_SPLIT_P = 0x1
 PFA_FLAG_NO_XCD_MAP = 0x2
@@ -23,7 +23,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "libpfa_hip.so")
 
 EXPORTS = (
     "pfa_abi_version", "pfa_status_string", "pfa_device_supported", "pfa_last_hip_error",
-    "pfa_fa3_workspace_bytes", "pfa_fa3_check", "pfa_fa3_fwd", "pfa_fa3_describe",
+    "pfa_fa3_workspace_bytes", "pfa_fa3_check", "pfa_fa3_fwd", "pfa_fa3_describe", "pfa_fa3_weights",
 )
 
 
@@ -42,6 +42,9 @@ class PfaFa3Args(C.Structure):
         ("dtype_in", C.c_int32), ("dtype_out", C.c_int32), ("causal", C.c_int32),
         ("softmax_scale", C.c_float), ("device_id", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("mask", C.c_void_p),
+        ("mask_stride_b", C.c_int64), ("mask_stride_h", C.c_int64), ("mask_stride_q", C.c_int64),
+        ("mask_stride_k", C.c_int64),
     ]
 
 
@@ -83,6 +86,9 @@ def load(path: Optional[str] = None):
         lib.pfa_fa3_check.argtypes = [C.POINTER(PfaFa3Args)]
         lib.pfa_fa3_fwd.restype = C.c_int
         lib.pfa_fa3_fwd.argtypes = [C.POINTER(PfaFa3Args), C.c_void_p]
+        lib.pfa_fa3_weights.restype = C.c_int
+        lib.pfa_fa3_weights.argtypes = [C.POINTER(PfaFa3Args), C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
+                                        C.c_void_p]
         lib.pfa_fa3_describe.restype = C.c_int
         lib.pfa_fa3_describe.argtypes = [C.POINTER(PfaFa3Args), C.c_char_p, C.c_size_t]
         v = lib.pfa_abi_version()

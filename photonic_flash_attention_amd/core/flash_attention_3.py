@@ -71,9 +71,11 @@ class FlashAttention3(nn.Module):
     ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
         """query/key/value: ``[B, S, E]``.  Returns ``(output [B,S,E], weights or None)``.
 
-        ``attention_mask``: ``None`` or a 2-D ``[B, Sk]`` key mask (0 = masked).  Causality,
-        which the reference can only express as a dense 4-D mask, is the ``is_causal`` flag here
-        (an addition to the reference signature); other 4-D masks are not yet supported."""
+        ``attention_mask``: ``None``, a 2-D ``[B, Sk]`` key mask, or a 3-D/4-D mask broadcastable to
+        ``[B, H, Sq, Sk]`` (0 = masked, as in the reference).  Causality, which the reference can only
+        express as a dense 4-D mask, is also available as the ``is_causal`` flag (an addition to the
+        reference signature; it costs no mask traffic and skips the masked half of the work).
+        ``need_weights=True`` returns the true softmax matrix ``[B,H,Sq,Sk]`` from a second kernel pass."""
         profile = get_config().enable_profiling and query.is_cuda
         if profile:
             start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -133,26 +135,20 @@ class FlashAttention3(nn.Module):
             raise RuntimeError("forward-only kernel: call under torch.no_grad() (backward is not implemented)")
         if self.training and self.dropout > 0:
             raise NotImplementedError("attention dropout in training mode is not implemented on the HIP path")
-        if need_weights:
-            raise NotImplementedError("need_weights=True is not implemented on the HIP path yet")
 
-        key_mask = None
-        if attention_mask is not None:
-            if attention_mask.dim() == 2:
-                key_mask = attention_mask
-            else:
-                raise NotImplementedError(
-                    "only 2-D [B,Sk] key masks and is_causal=True are supported; got a "
-                    f"{attention_mask.dim()}-D attention_mask")
+        # 2-D [B,Sk] masks take the cheap key-mask path (:166-167); 3-D / 4-D masks the general one (:168,:235)
+        key_mask = attention_mask if (attention_mask is not None and attention_mask.dim() == 2) else None
+        mask = attention_mask if (attention_mask is not None and attention_mask.dim() != 2) else None
 
-        io_dtype = q.dtype
-        if io_dtype == torch.float32:
+        kw = dict(causal=is_causal, key_mask=key_mask, mask=mask, softmax_scale=self.scaling,
+                  return_weights=need_weights)
+        if q.dtype == torch.float32:
             cd = self.compute_dtype
-            out, _ = ops.fa3_forward(q.to(cd), k.to(cd), v.to(cd), causal=is_causal, key_mask=key_mask,
-                                     softmax_scale=self.scaling, out_dtype=torch.float32)
+            res = ops.fa3_forward(q.to(cd), k.to(cd), v.to(cd), out_dtype=torch.float32,
+                                  weights_dtype=torch.float32, **kw)
         else:
-            out, _ = ops.fa3_forward(q, k, v, causal=is_causal, key_mask=key_mask, softmax_scale=self.scaling)
-        return out, None
+            res = ops.fa3_forward(q, k, v, **kw)
+        return res[0], (res[2] if need_weights else None)
 
     def get_performance_stats(self) -> dict:
         """Same keys as the reference (:295-302)."""

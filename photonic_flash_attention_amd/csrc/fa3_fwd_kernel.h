@@ -48,12 +48,12 @@ struct FwdParams {
     void* o;
     float* lse;
     const int32_t* seqlens_k;
-    const uint8_t* key_mask;
+    const uint8_t* mask;       // optional u8 mask, 0 = masked, addressed [b][h][q][k] by the four byte strides below
     int64_t q_sb, q_sh, q_ss;
     int64_t k_sb, k_sh, k_ss;
     int64_t v_sb, v_sh, v_ss;
     int64_t o_sb, o_sh, o_ss;
-    int64_t km_sb;
+    int64_t m_sb, m_sh, m_sq, m_sk;   // a 2-D [B,Sk] key mask is (stride, 0, 0, 1)
     int32_t B, H, Sq, Sk;
     int32_t nqblk;        // ceil(Sq / BLOCK_M)
     float scale_log2;     // softmax_scale * log2(e)
@@ -224,7 +224,8 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
     const T* __restrict__ qp = (const T*)p.q + (int64_t)b * p.q_sb + (int64_t)hh * p.q_sh;
     const T* __restrict__ kp = (const T*)p.k + (int64_t)b * p.k_sb + (int64_t)hh * p.k_sh;
     const T* __restrict__ vp = (const T*)p.v + (int64_t)b * p.v_sb + (int64_t)hh * p.v_sh;
-    const uint8_t* __restrict__ kmp = KMASK ? p.key_mask + (int64_t)b * p.km_sb : nullptr;
+    const uint8_t* __restrict__ kmp =
+        KMASK ? p.mask + (int64_t)b * p.m_sb + (int64_t)hh * p.m_sh + (int64_t)min(my_q, p.Sq - 1) * p.m_sq : nullptr;
 
     // ---- Q fragments: B operand of S^T = K Q^T, lane (r,h) holds Q[my_q][16 ks + 8 h .. +7] -----------
     v8 qf[KS];
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
                     const int key = key_base + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
                     bool ok = key < kv_len;
                     if (CAUSAL) ok = ok && (key <= my_q);
-                    if (KMASK) ok = ok && (kmp[min(key, p.Sk - 1)] != 0);
+                    if (KMASK) ok = ok && (kmp[(int64_t)min(key, p.Sk - 1) * p.m_sk] != 0);
                     s[kb][e] = ok ? s[kb][e] : -INFINITY;
                 }
         }

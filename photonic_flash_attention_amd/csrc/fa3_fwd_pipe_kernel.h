@@ -72,7 +72,8 @@ __global__ __launch_bounds__(512, 2) void fa3_fwd_pipe_kernel(const FwdParams p)
     const T* __restrict__ qp = (const T*)p.q + (int64_t)b * p.q_sb + (int64_t)hh * p.q_sh;
     const T* __restrict__ kp = (const T*)p.k + (int64_t)b * p.k_sb + (int64_t)hh * p.k_sh;
     const T* __restrict__ vp = (const T*)p.v + (int64_t)b * p.v_sb + (int64_t)hh * p.v_sh;
-    const uint8_t* __restrict__ kmp = KMASK ? p.key_mask + (int64_t)b * p.km_sb : nullptr;
+    const uint8_t* __restrict__ kmp =
+        KMASK ? p.mask + (int64_t)b * p.m_sb + (int64_t)hh * p.m_sh + (int64_t)min(my_q, p.Sq - 1) * p.m_sq : nullptr;
 
     // Q fragments (B operand of S^T = K Q^T)
     v8 qf[KS];
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void fa3_fwd_pipe_kernel(const FwdParams p)
                 const int key = key_base + (e & 3) + 8 * (e >> 2) + 4 * h;
                 bool ok = key < kv_len;
                 if (CAUSAL) ok = ok && (key <= my_q);
-                if (KMASK) ok = ok && (kmp[min(key, p.Sk - 1)] != 0);
+                if (KMASK) ok = ok && (kmp[(int64_t)min(key, p.Sk - 1) * p.m_sk] != 0);
                 s[e] = ok ? s[e] : -INFINITY;
             }
         }

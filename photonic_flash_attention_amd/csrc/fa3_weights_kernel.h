@@ -1,0 +1,113 @@
+// fa3_weights_kernel.h -- attention weights P = softmax(scale * Q K^T + mask), materialised [B,H,Sq,Sk].
+//
+// The reference returns them on request (need_weights=True): the dense branch hands back the softmax matrix
+// (core/flash_attention_3.py:171,180), the tiled branch a per-tile, never re-normalised slice (:257-258, row sums
+// 1.4-1.6 -- a reference defect we do not reproduce).  Here the weights are always the true softmax: a second,
+// memory-bound pass recomputes S = Q K^T with the same swapped 32x32x16 MFMA product as the forward kernel and
+// writes exp2(c*s - lse*log2e) using the forward pass's LSE.  Traffic = B*H*Sq*Sk output elements, which is why
+// the forward kernel never writes them unless asked.
+//
+// Workgroup = 4 waves x 32 query rows; every wave walks the key sequence in 32-key blocks, K fragments straight
+// from global/L2 to registers (all waves of a block read the same K rows; no LDS).  Fully masked key blocks of a
+// causal problem are skipped: the host zero-fills W first.
+#pragma once
+#include "fa3_fwd_kernel.h"
+
+namespace pfa {
+
+struct WeightsParams {
+    const void* q;
+    const void* k;
+    const float* lse;          // [B,H,Sq] natural-log LSE from the forward pass
+    void* w;                   // [B,H,Sq,Sk] by strides, last dim contiguous
+    const int32_t* seqlens_k;
+    const uint8_t* mask;
+    int64_t q_sb, q_sh, q_ss;
+    int64_t k_sb, k_sh, k_ss;
+    int64_t w_sb, w_sh, w_sq;
+    int64_t m_sb, m_sh, m_sq, m_sk;
+    int32_t B, H, Sq, Sk;
+    int32_t nqblk;
+    float scale_log2;
+};
+
+template <typename T, int D, bool CAUSAL, bool KMASK, typename WT>
+__global__ __launch_bounds__(256) void fa3_weights_kernel(const WeightsParams p) {
+    using E = Elem<T>;
+    using v8 = typename E::v8;
+    constexpr int KS = D / 16;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31;
+    const int h = lane >> 5;
+    const int BH = p.B * p.H;
+    const int n = blockIdx.x;
+    const int qblk = n / BH;
+    const int bh = n - qblk * BH;
+    const int b = bh / p.H;
+    const int hh = bh - b * p.H;
+    const int wave_q0 = qblk * 128 + wave * 32;
+    const int my_q = wave_q0 + r;
+    if (wave_q0 >= p.Sq) return;
+
+    int kv_len = p.Sk;
+    if (p.seqlens_k) kv_len = min(kv_len, max(p.seqlens_k[b], 0));
+    const int kv_end = CAUSAL ? min(kv_len, wave_q0 + 32) : kv_len;   // keys any row of this wave can see
+
+    const T* __restrict__ qp = (const T*)p.q + (int64_t)b * p.q_sb + (int64_t)hh * p.q_sh;
+    const T* __restrict__ kp = (const T*)p.k + (int64_t)b * p.k_sb + (int64_t)hh * p.k_sh;
+    const int qrow = min(my_q, p.Sq - 1);
+    const uint8_t* __restrict__ mp =
+        KMASK ? p.mask + (int64_t)b * p.m_sb + (int64_t)hh * p.m_sh + (int64_t)qrow * p.m_sq : nullptr;
+    WT* __restrict__ wrow = (WT*)p.w + (int64_t)b * p.w_sb + (int64_t)hh * p.w_sh + (int64_t)qrow * p.w_sq;
+
+    v8 qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const v8*)(qp + (int64_t)qrow * p.q_ss + 16 * ks + 8 * h);
+    const float lse = p.lse[((int64_t)b * p.H + hh) * p.Sq + qrow];
+    const float c = p.scale_log2;
+    const float lse2 = lse * 1.4426950408889634f;      // -inf for a fully masked row -> weights 0 below
+    const bool dead_row = !(lse > -INFINITY);
+
+    for (int key_base = 0; key_base < kv_end; key_base += 32) {
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+        const int krow = min(key_base + r, p.Sk - 1);
+        const T* ksrc = kp + (int64_t)krow * p.k_ss + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) s = E::mfma(*(const v8*)(ksrc + 16 * ks), qf[ks], s);
+        // lane (r,h) now holds S[my_q][key_base + (e&3) + 8(e>>2) + 4h]
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int key0 = key_base + 8 * g + 4 * h;
+            float w4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = key0 + e;
+                bool ok = key < kv_len && !dead_row;
+                if (CAUSAL) ok = ok && (key <= my_q);
+                if (KMASK) ok = ok && (mp[(int64_t)min(key, p.Sk - 1) * p.m_sk] != 0);
+                w4[e] = ok ? fast_exp2(__builtin_fmaf(s[4 * g + e], c, -lse2)) : 0.f;
+            }
+            if (my_q < p.Sq) {
+                if (key0 + 3 < p.Sk && ((reinterpret_cast<uintptr_t>(wrow + key0) & (4 * sizeof(WT) - 1)) == 0)) {
+                    if constexpr (sizeof(WT) == 4) {
+                        *(f32x4*)(wrow + key0) = f32x4{w4[0], w4[1], w4[2], w4[3]};
+                    } else {
+                        typename E::v4 t;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) t[e] = (T)w4[e];
+                        *(typename E::v4*)(wrow + key0) = t;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (key0 + e < p.Sk) wrow[key0 + e] = (WT)w4[e];
+                }
+            }
+        }
+    }
+}
+
+}  // namespace pfa

@@ -11,6 +11,7 @@
 #include "fa3_fwd_kernel.h"
 #include "fa3_fwd_pipe_kernel.h"
 #include "fa3_fwd_stagger_kernel.h"
+#include "fa3_weights_kernel.h"
 
 namespace {
 
@@ -69,7 +70,8 @@ Variant exp_variant(bool causal) {
 }
 
 Variant pick(const pfa_fa3_args* a) {
-    const bool causal = a->causal != 0, split = (a->flags & PFA_FLAG_SPLIT_P) != 0, kmask = a->key_mask != nullptr;
+    const bool causal = a->causal != 0, split = (a->flags & PFA_FLAG_SPLIT_P) != 0;
+    const bool kmask = a->key_mask != nullptr || a->mask != nullptr;
     const bool out32 = a->dtype_out == PFA_DTYPE_FP32;
     const unsigned var = (a->flags >> 8) & 0xffu;   // 0 = production default
     if (var != 0 && a->dtype_in == PFA_DTYPE_BF16 && a->D == 128 && !split && !kmask && !out32) {
@@ -99,6 +101,7 @@ int check(const pfa_fa3_args* a) {
     if (a->size != sizeof(pfa_fa3_args)) return PFA_ERR_STRUCT_SIZE;
     if (a->flags & ~(PFA_FLAG_SPLIT_P | PFA_FLAG_NO_XCD_MAP | PFA_FLAG_VARIANT_MASK)) return PFA_ERR_FLAGS;
     if (!a->q || !a->k || !a->v || !a->o) return PFA_ERR_NULL;
+    if (a->key_mask && a->mask) return PFA_ERR_FLAGS;
     if (a->B <= 0 || a->H <= 0 || a->Sq <= 0 || a->Sk <= 0) return PFA_ERR_SHAPE;
     if (a->D != 64 && a->D != 128) return PFA_ERR_HEAD_DIM;
     if (a->dtype_in != PFA_DTYPE_BF16 && a->dtype_in != PFA_DTYPE_FP16) return PFA_ERR_DTYPE;
@@ -125,6 +128,18 @@ int check(const pfa_fa3_args* a) {
 
 }  // namespace
 
+namespace {
+template <typename T, int D, bool C, bool K>
+const void* weights_fn(bool w32) {
+    return w32 ? (const void*)&pfa::fa3_weights_kernel<T, D, C, K, float> : (const void*)&pfa::fa3_weights_kernel<T, D, C, K, T>;
+}
+template <typename T, int D>
+const void* weights_fn_ck(bool causal, bool kmask, bool w32) {
+    if (causal) return kmask ? weights_fn<T, D, true, true>(w32) : weights_fn<T, D, true, false>(w32);
+    return kmask ? weights_fn<T, D, false, true>(w32) : weights_fn<T, D, false, false>(w32);
+}
+}  // namespace
+
 extern "C" {
 
 int pfa_abi_version(void) { return PFA_ABI_VERSION; }
@@ -141,7 +156,7 @@ const char* pfa_status_string(int status) {
         case PFA_ERR_ALIGN: return "q/k/v/o base pointers must be 16-byte aligned";
         case PFA_ERR_DEVICE: return "device is not a supported gfx950 part";
         case PFA_ERR_LAUNCH: return "HIP kernel launch failed";
-        case PFA_ERR_FLAGS: return "unknown flag bits";
+        case PFA_ERR_FLAGS: return "unknown flag bits, or both key_mask and mask set";
         default: return "unknown pfa_status";
     }
 }
@@ -184,12 +199,16 @@ int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream) {
 
     pfa::FwdParams p;
     p.q = a->q; p.k = a->k; p.v = a->v; p.o = a->o;
-    p.lse = a->lse; p.seqlens_k = a->seqlens_k; p.key_mask = a->key_mask;
+    p.lse = a->lse; p.seqlens_k = a->seqlens_k;
+    if (a->mask) {
+        p.mask = a->mask; p.m_sb = a->mask_stride_b; p.m_sh = a->mask_stride_h; p.m_sq = a->mask_stride_q; p.m_sk = a->mask_stride_k;
+    } else {
+        p.mask = a->key_mask; p.m_sb = a->key_mask_stride_b; p.m_sh = 0; p.m_sq = 0; p.m_sk = 1;
+    }
     p.q_sb = a->q_stride_b; p.q_sh = a->q_stride_h; p.q_ss = a->q_stride_s;
     p.k_sb = a->k_stride_b; p.k_sh = a->k_stride_h; p.k_ss = a->k_stride_s;
     p.v_sb = a->v_stride_b; p.v_sh = a->v_stride_h; p.v_ss = a->v_stride_s;
     p.o_sb = a->o_stride_b; p.o_sh = a->o_stride_h; p.o_ss = a->o_stride_s;
-    p.km_sb = a->key_mask_stride_b;
     p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
     p.dbg = (unsigned long long*)a->workspace;   // only the diagnostic VAR_STAMP variant writes it
     const Variant v = pick(a);
@@ -209,6 +228,55 @@ int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream) {
     if (v.lds_bytes > 64 * 1024)   // opt in to > 64 KiB of dynamic LDS (idempotent, per function)
         (void)hipFuncSetAttribute(v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds_bytes);
     e = hipLaunchKernel(v.fn, dim3(grid), dim3(v.nthreads), kargs, (size_t)v.lds_bytes, (hipStream_t)stream);
+    if (prev_dev != a->device_id) (void)hipSetDevice(prev_dev);
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        (void)hipGetLastError();
+        return PFA_ERR_LAUNCH;
+    }
+    return PFA_OK;
+}
+
+int pfa_fa3_weights(const pfa_fa3_args* a, void* w, int32_t w_dtype, int64_t w_stride_b, int64_t w_stride_h,
+                    int64_t w_stride_q, void* stream) {
+    if (!a || !w) return PFA_ERR_NULL;
+    pfa_fa3_args probe = *a;             // same validation as the forward; v/o are not read here
+    if (!probe.v) probe.v = probe.k;
+    if (!probe.o) probe.o = w;
+    const int st = check(&probe);
+    if (st != PFA_OK) return st;
+    if (!a->lse) return PFA_ERR_NULL;
+    if (w_dtype != a->dtype_in && w_dtype != PFA_DTYPE_FP32) return PFA_ERR_DTYPE;
+
+    pfa::WeightsParams p;
+    p.q = a->q; p.k = a->k; p.lse = a->lse; p.w = w; p.seqlens_k = a->seqlens_k;
+    if (a->mask) {
+        p.mask = a->mask; p.m_sb = a->mask_stride_b; p.m_sh = a->mask_stride_h; p.m_sq = a->mask_stride_q; p.m_sk = a->mask_stride_k;
+    } else {
+        p.mask = a->key_mask; p.m_sb = a->key_mask_stride_b; p.m_sh = 0; p.m_sq = 0; p.m_sk = 1;
+    }
+    p.q_sb = a->q_stride_b; p.q_sh = a->q_stride_h; p.q_ss = a->q_stride_s;
+    p.k_sb = a->k_stride_b; p.k_sh = a->k_stride_h; p.k_ss = a->k_stride_s;
+    p.w_sb = w_stride_b; p.w_sh = w_stride_h; p.w_sq = w_stride_q;
+    p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
+    p.nqblk = (a->Sq + 127) / 128;
+    p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
+    const bool causal = a->causal != 0, kmask = p.mask != nullptr, w32 = w_dtype == PFA_DTYPE_FP32;
+    const void* fn;
+    if (a->dtype_in == PFA_DTYPE_BF16)
+        fn = a->D == 128 ? weights_fn_ck<__bf16, 128>(causal, kmask, w32) : weights_fn_ck<__bf16, 64>(causal, kmask, w32);
+    else
+        fn = a->D == 128 ? weights_fn_ck<_Float16, 128>(causal, kmask, w32) : weights_fn_ck<_Float16, 64>(causal, kmask, w32);
+    int prev_dev = -1;
+    hipError_t e = hipGetDevice(&prev_dev);
+    if (e == hipSuccess && prev_dev != a->device_id) e = hipSetDevice(a->device_id);
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        (void)hipGetLastError();
+        return PFA_ERR_DEVICE;
+    }
+    void* kargs[] = {&p};
+    e = hipLaunchKernel(fn, dim3((unsigned)(p.nqblk * a->B * a->H)), dim3(256), kargs, 0, (hipStream_t)stream);
     if (prev_dev != a->device_id) (void)hipSetDevice(prev_dev);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;

@@ -174,7 +174,7 @@ class PhotonicMultiHeadAttention(PhotonicFlashAttention):
             if attention_mask is not None:
                 attention_mask = attention_mask + key_padding_mask.unsqueeze(1)
             else:
-                attention_mask = key_padding_mask  # [B,Sk]; the reference unsqueezes to [B,1,Sk] (:315)
+                attention_mask = key_padding_mask  # [B,Sk] key mask; the reference unsqueezes to [B,1,Sk] (:315)
 
         result = super().forward(query, key, value, attention_mask, need_weights, is_causal=is_causal)
         if need_weights:

@@ -45,8 +45,28 @@ def _bhsd_strides(t: torch.Tensor):
     return sb, sh, ss
 
 
+def _as_mask4(mask: torch.Tensor, B: int, H: int, Sq: int, Sk: int, device) -> torch.Tensor:
+    """Normalise a reference-style mask (0 = masked) to a u8 tensor broadcastable as [B,H,Sq,Sk].
+    2-D [B,Sk] -> [B,1,1,Sk] (flash_attention_3.py:166-167); 3-D [B,Sq|1,Sk] -> [B,1,Sq|1,Sk]; 4-D as is."""
+    if mask.dim() == 2:
+        mask = mask[:, None, None, :]
+    elif mask.dim() == 3:
+        mask = mask[:, None, :, :]
+    elif mask.dim() != 4:
+        raise ValueError(f"attention mask must be 2-D, 3-D or 4-D, got {mask.dim()}-D")
+    for got, want, name in zip(mask.shape, (B, H, Sq, Sk), "BHQK"):
+        if got not in (1, want):
+            raise ValueError(f"mask dim {name} is {got}, expected 1 or {want}")
+    if mask.shape[3] != Sk:
+        mask = mask.expand(-1, -1, -1, Sk)
+    m = (mask != 0).to(device=device, dtype=torch.uint8)
+    if m.stride(3) not in (0, 1) or (m.shape[3] > 1 and m.stride(3) == 0):
+        m = m.contiguous()
+    return m
+
+
 def build_args(q, k, v, out, *, causal=False, seqlens_k=None, key_mask=None, softmax_scale=None,
-               lse=None, split_p=False, variant=0):
+               lse=None, split_p=False, variant=0, mask=None):
     """Fill a ``pfa_fa3_args`` from ``[B,H,S,D]``-shaped (arbitrarily strided) tensors."""
     B, H, Sq, D = q.shape
     Sk = k.shape[2]
@@ -88,6 +108,14 @@ def build_args(q, k, v, out, *, causal=False, seqlens_k=None, key_mask=None, sof
         a.key_mask = km.data_ptr()
         a.key_mask_stride_b = km.stride(0)
         keep.append(km)
+    if mask is not None:
+        if key_mask is not None:
+            raise ValueError("pass either key_mask or mask")
+        m4 = _as_mask4(mask, B, H, Sq, Sk, q.device)
+        a.mask = m4.data_ptr()
+        st = [0 if m4.shape[i] == 1 else m4.stride(i) for i in range(4)]
+        a.mask_stride_b, a.mask_stride_h, a.mask_stride_q, a.mask_stride_k = st[0], st[1], st[2], (st[3] or 1)
+        keep.append(m4)
     if lse is not None:
         if lse.shape != (B, H, Sq) or lse.dtype != torch.float32 or not lse.is_contiguous():
             raise ValueError("lse must be contiguous fp32 [B, H, Sq]")
@@ -96,14 +124,18 @@ def build_args(q, k, v, out, *, causal=False, seqlens_k=None, key_mask=None, sof
 
 
 def fa3_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: bool = False,
-                seqlens_k=None, key_mask: Optional[torch.Tensor] = None,
+                seqlens_k=None, key_mask: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
                 softmax_scale: Optional[float] = None, out_dtype: Optional[torch.dtype] = None,
-                return_lse: bool = False, split_p: Optional[bool] = None,
+                return_lse: bool = False, return_weights: bool = False, weights_dtype: Optional[torch.dtype] = None,
+                split_p: Optional[bool] = None,
                 out: Optional[torch.Tensor] = None, _variant: Optional[int] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """softmax(scale * q k^T + mask) v on the MI355X kernel.
 
     q: ``[B,H,Sq,D]``, k/v: ``[B,H,Sk,D]`` (any batch/head/seq strides that are multiples of 8
-    elements; head_dim contiguous).  Returns ``(out [B,H,Sq,D] view of a [B,Sq,H,D] buffer, lse or None)``.
+    elements; head_dim contiguous).  Returns ``(out [B,H,Sq,D] view of a [B,Sq,H,D] buffer, lse or None)``;
+    with ``return_weights=True`` a third element, the softmax matrix ``[B,H,Sq,Sk]`` (second kernel pass,
+    the reference's ``need_weights``).  ``mask``: any 2-/3-/4-D reference-style mask (0 = masked);
+    ``key_mask``: the cheaper ``[B,Sk]`` special case.
 
     ``out_dtype=torch.float32`` selects the parity variant: fp32 store and, unless
     ``split_p=False`` is forced, P carried as bf16 hi+lo so the result is within 1e-3 of the
@@ -117,20 +149,34 @@ def fa3_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: bo
         split_p = odt == torch.float32
     if out is None:
         out = torch.empty((B, Sq, H, D), dtype=odt, device=q.device).permute(0, 2, 1, 3)
-    lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device) if return_lse else None
-    args, keep = build_args(q, k, v, out, causal=causal, seqlens_k=seqlens_k, key_mask=key_mask,
+    lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device) if (return_lse or return_weights) else None
+    args, keep = build_args(q, k, v, out, causal=causal, seqlens_k=seqlens_k, key_mask=key_mask, mask=mask,
                             softmax_scale=softmax_scale, lse=lse, split_p=split_p, variant=_variant)
     stream = torch.cuda.current_stream(q.device).cuda_stream
     st = _capi.load().pfa_fa3_fwd(C.byref(args), C.c_void_p(stream))
     if st in (-3, -4, -5, -6, -7, -10):
         raise ValueError(f"pfa_fa3_fwd: {_capi.status_string(st)}")
     _capi.check_status(st)
-    for t in keep:   # tensors made here must outlive the enqueued kernel
+    weights = None
+    if return_weights:
+        Sk = k.shape[2]
+        wdt = q.dtype if weights_dtype is None else weights_dtype
+        # causal / ragged problems skip fully masked key blocks, so those must read as zeros
+        alloc = torch.zeros if (causal or seqlens_k is not None) else torch.empty
+        weights = alloc((B, H, Sq, Sk), dtype=wdt, device=q.device)
+        stw = _capi.load().pfa_fa3_weights(C.byref(args), C.c_void_p(weights.data_ptr()), _DT[wdt],
+                                           weights.stride(0), weights.stride(1), weights.stride(2), C.c_void_p(stream))
+        if stw in (-3, -4, -5, -6, -7, -10):
+            raise ValueError(f"pfa_fa3_weights: {_capi.status_string(stw)}")
+        _capi.check_status(stw)
+    for t in keep:   # tensors made here must outlive the enqueued kernels
         t.record_stream(torch.cuda.current_stream(q.device))
+    if return_weights:
+        return out, (lse if return_lse else None), weights
     return out, lse
 
 
 def fa3_forward_bshd(q, k, v, **kw):
     """Same, for operands laid out ``[B,S,H,D]``; returns ``[B,Sq,H,D]`` (+ lse)."""
-    o, lse = fa3_forward(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), **kw)
-    return o.permute(0, 2, 1, 3), lse
+    res = fa3_forward(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), **kw)
+    return (res[0].permute(0, 2, 1, 3),) + tuple(res[1:])

@@ -1,0 +1,181 @@
+"""GPU tests of the reference-shaped modules and of the rank-2 "next" rows of SURVEY.md section 8(f):
+general 4-D masks and need_weights, all through the C ABI.  The assertions re-express what the
+reference's own unit tests pin (tests/unit/test_flash_attention_3.py of the reference: shapes/dtype :51-53,
+weights shape / row-sum 1 +- 1e-3 / non-negative :71-79, mask changes output :104-115, Sq != Skv :117-135,
+eval determinism :186-191, batch sizes :232-247, (E,H) grid :264-285, stats keys :221-229)."""
+
+from __future__ import annotations
+
+import pytest
+import torch
+
+from conftest import load_golden
+from photonic_flash_attention_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _oracle():
+    from oracle import fa3_oracle as orc
+    return orc
+
+
+def _state(E, seed):
+    return {
+        "qkv_proj.weight": torch.from_numpy(synth.normal_f32((3 * E, E), seed + 10)) * E ** -0.5,
+        "qkv_proj.bias": torch.from_numpy(synth.normal_f32((3 * E,), seed + 11)) * 0.1,
+        "out_proj.weight": torch.from_numpy(synth.normal_f32((E, E), seed + 12)) * E ** -0.5,
+        "out_proj.bias": torch.from_numpy(synth.normal_f32((E,), seed + 13)) * 0.1,
+    }
+
+
+def test_general_4d_mask_matches_reference_golden():
+    """g4 fixtures were produced by the reference with a 4-D mask; feed the same 4-D mask through `mask=`."""
+    from photonic_flash_attention_amd import ops
+    for name in ("g4_s640_d64_kvtail", "g4_s640_d128_kvtail_causal"):
+        meta, arr = load_golden(name)
+        q, k, v = synth.qkv(meta["B"], meta["H"], meta["Sq"], meta["Sk"], meta["D"], meta["seed"], "bf16")
+        Sq, Sk = meta["Sq"], meta["Sk"]
+        m = (torch.arange(Sk) < meta["kv_valid"]).view(1, 1, 1, Sk).expand(meta["B"], 1, Sq, Sk)
+        if meta["causal"]:
+            m = m & torch.tril(torch.ones(Sq, Sk, dtype=torch.bool)).view(1, 1, Sq, Sk)
+        o, _ = ops.fa3_forward_bshd(q.to(DEV), k.to(DEV), v.to(DEV), mask=m.to(DEV), out_dtype=torch.float32)
+        err = float((o.cpu() - torch.from_numpy(arr["out"])).abs().max())
+        assert err <= 1e-3, (name, err)
+
+
+def test_random_4d_mask_and_broadcast_forms():
+    from photonic_flash_attention_amd import ops
+    orc = _oracle()
+    B, H, Sq, Sk, D = 2, 3, 200, 333, 64
+    q, k, v = synth.qkv(B, H, Sq, Sk, D, 77, "bf16")
+    g = torch.Generator().manual_seed(5)
+    for shape in [(B, H, Sq, Sk), (1, 1, Sq, Sk), (B, 1, 1, Sk), (1, H, Sq, Sk)]:
+        m = torch.rand(shape, generator=g) > 0.4
+        m[..., 0] = True                       # keep every row alive (parity domain)
+        ref = orc.flash_attention_forward(q.float().permute(0, 2, 1, 3), k.float().permute(0, 2, 1, 3),
+                                          v.float().permute(0, 2, 1, 3), m.expand(B, H, Sq, Sk)).permute(0, 2, 1, 3)
+        o, _ = ops.fa3_forward_bshd(q.to(DEV), k.to(DEV), v.to(DEV), mask=m.to(DEV), out_dtype=torch.float32)
+        assert float((o.cpu() - ref).abs().max()) <= 1e-3, shape
+
+
+@pytest.mark.parametrize("case", [(2, 2, 128, 128, 64, False), (1, 3, 300, 517, 128, False), (1, 2, 384, 384, 64, True)])
+def test_attention_weights_are_the_true_softmax(case):
+    from photonic_flash_attention_amd import ops
+    B, H, Sq, Sk, D, causal = case
+    q, k, v = synth.qkv(B, H, Sq, Sk, D, 31, "bf16")
+    o, _, w = ops.fa3_forward_bshd(q.to(DEV), k.to(DEV), v.to(DEV), causal=causal, return_weights=True,
+                                   weights_dtype=torch.float32, out_dtype=torch.float32)
+    s = torch.matmul(q.double().permute(0, 2, 1, 3), k.double().permute(0, 2, 3, 1)) * D ** -0.5
+    if causal:
+        s = s.masked_fill(~torch.tril(torch.ones(Sq, Sk, dtype=torch.bool)), float("-inf"))
+    ref = torch.softmax(s, dim=-1).float()
+    w = w.cpu()
+    assert w.shape == (B, H, Sq, Sk)
+    assert float((w - ref).abs().max()) <= 1e-4
+    assert bool((w >= 0).all()) and float((w.sum(-1) - 1).abs().max()) <= 1e-3      # reference test :75-79
+    # and P V reproduces the kernel's own output
+    pv = torch.matmul(w.double(), v.double().permute(0, 2, 1, 3)).permute(0, 2, 1, 3).float()
+    assert float((pv - o.cpu()).abs().max()) <= 1e-3
+
+
+def test_module_forward_matches_reference_module_golden():
+    """Whole PhotonicFlashAttention forward on the GPU (projections by hipBLASLt through nn.Linear + our
+    kernel) against the real reference module's fp32 CPU output (g1_c1_module, BASELINE config C1).
+    fp32 module -> bf16 attention operands: tolerance = bf16 input rounding, stated."""
+    from photonic_flash_attention_amd import PhotonicFlashAttention
+    meta, arr = load_golden("g1_c1_module")
+    E, H, seed = meta["E"], meta["H"], meta["seed"]
+    m = PhotonicFlashAttention(E, H).eval()
+    m.gpu_attention.load_state_dict(_state(E, seed))
+    m = m.to(DEV)
+    x = torch.from_numpy(synth.normal_f32((meta["B"], meta["S"], E), seed)).to(DEV)
+    with torch.no_grad():
+        y = m(x)
+    assert isinstance(y, torch.Tensor) and y.shape == x.shape and y.dtype == x.dtype and y.device == x.device
+    err = float((y.cpu() - torch.from_numpy(arr["out"])).abs().max())
+    print(f"module vs reference module: max-abs {err:.3e}")
+    assert err <= 3e-2
+    assert m.last_device_used == "gpu" and m.get_performance_stats()["gpu_calls"] == 1
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cfg", [(2, 128, 512, 8), (4, 256, 768, 12), (1, 512, 1024, 16), (2, 96, 384, 6)])
+def test_module_contract_like_reference_unit_tests(cfg, dtype):
+    from photonic_flash_attention_amd import FlashAttention3
+    orc = _oracle()
+    B, S, E, H = cfg
+    m = FlashAttention3(E, H, dtype=dtype).to(DEV).eval()
+    x = torch.from_numpy(synth.normal_f32((B, S, E), 3)).to(DEV, dtype)
+    mask = torch.ones(B, S, dtype=torch.bool, device=DEV)
+    mask[:, S - S // 10:] = False                                    # conftest.py:41-59 of the reference
+    with torch.no_grad():
+        out, w0 = m(x)
+        out2, _ = m(x)
+        outm, _ = m(x, attention_mask=mask)
+        outw, w = m(x, need_weights=True)
+    assert w0 is None and out.shape == (B, S, E) and out.dtype == dtype and out.device == x.device
+    assert bool(torch.isfinite(out.float()).all()) and float(out.float().abs().max()) > 0
+    assert torch.equal(out, out2)                                    # eval-mode determinism
+    assert not torch.allclose(out.float(), outm.float())            # mask changes the output
+    assert w.shape == (B, H, S, S) and bool((w >= 0).all())
+    assert float((w.float().sum(-1) - 1).abs().max()) <= (1e-3 if dtype == torch.float16 else 8e-3)
+    assert torch.equal(out, outw)
+    # numbers: same weights in the oracle's module restatement, fp32
+    sd = {k_: v_.float().cpu() for k_, v_ in m.state_dict().items()}
+    ref = orc.module_forward(sd, H, x.float().cpu())
+    tol = 3e-2 if dtype == torch.bfloat16 else 6e-3
+    assert float((out.float().cpu() - ref).abs().max()) <= tol
+    assert set(m.get_performance_stats()) == {"latency_ms", "memory_mb", "device", "implementation"}
+
+
+def test_cross_attention_and_mha_facade():
+    from photonic_flash_attention_amd import FlashAttention3, PhotonicMultiHeadAttention
+    orc = _oracle()
+    E, H = 256, 4
+    m = FlashAttention3(E, H, dtype=torch.bfloat16).to(DEV).eval()
+    xq = torch.from_numpy(synth.normal_f32((2, 100, E), 1)).to(DEV, torch.bfloat16)
+    xkv = torch.from_numpy(synth.normal_f32((2, 333, E), 2)).to(DEV, torch.bfloat16)
+    with torch.no_grad():
+        y, _ = m(xq, xkv, xkv)                                     # Sq != Skv (reference test :117-135)
+    sd = {k_: v_.float().cpu() for k_, v_ in m.state_dict().items()}
+    ref = orc.module_forward(sd, H, xq.float().cpu(), xkv.float().cpu(), xkv.float().cpu())
+    assert y.shape == (2, 100, E) and float((y.float().cpu() - ref).abs().max()) <= 3e-2
+
+    mha = PhotonicMultiHeadAttention(E, H, batch_first=False, dtype=torch.bfloat16).to(DEV).eval()
+    x = xq.transpose(0, 1).contiguous()                              # (L, N, E)
+    kpm = torch.ones(2, 100, dtype=torch.bool, device=DEV)
+    kpm[:, 90:] = False                                              # reference semantics: 0 = masked
+    with torch.no_grad():
+        out, w = mha(x, x, x, key_padding_mask=kpm)                  # need_weights defaults to True
+        out_c, w_none = mha(x, x, x, need_weights=False, is_causal=True)
+    assert out.shape == (100, 2, E) and w.shape == (2, 100, 100) and w_none is None and out_c.shape == out.shape
+    assert float(w[:, :, 90:].abs().max()) == 0.0
+    assert float((w.float().sum(-1) - 1).abs().max()) <= 8e-3
+
+
+def test_hybrid_returns_raw_tuple_and_counts_gpu_samples():
+    from photonic_flash_attention_amd import HybridFlashAttention
+    h = HybridFlashAttention(512, 8, dtype=torch.bfloat16, max_concurrent_requests=2).to(DEV).eval()
+    x = torch.from_numpy(synth.normal_f32((8, 1024, 512), 4)).to(DEV, torch.bfloat16)   # B*S*S >> 1e6
+    with torch.no_grad():
+        for _ in range(12):
+            r = h(x, is_causal=True)
+    assert isinstance(r, tuple) and r[1] is None and r[0].shape == x.shape
+    st = h.get_performance_stats()
+    assert st["gpu_samples"] == 12 and st["photonic_samples"] == 0 and st["total_requests"] == 12
+
+
+def test_no_grad_required_and_dropout_rules():
+    from photonic_flash_attention_amd import FlashAttention3
+    m = FlashAttention3(128, 2, dropout=0.1, dtype=torch.bfloat16).to(DEV)
+    x = torch.zeros(1, 16, 128, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no_grad"):
+        m(x)
+    m.train()
+    with torch.no_grad(), pytest.raises(NotImplementedError):
+        m(x)
+    m.eval()
+    with torch.no_grad():
+        assert m(x)[0].shape == x.shape                               # dropout is a no-op in eval (:174-175)
