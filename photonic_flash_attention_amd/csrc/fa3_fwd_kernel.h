@@ -123,6 +123,16 @@ __device__ __forceinline__ float row_pair_sum(float x) {
 constexpr int VAR_DEFER_MAX = 1;   // T13: rescale O only when a row max grew by > 2^8 (else exact lazy rescale)
 constexpr int VAR_SETPRIO = 2;     // s_setprio(1) around the MFMA clusters
 constexpr int VAR_SCHED = 4;       // pin the QK^T read/MFMA interleave with sched_group_barrier
+// timing-only ablations (results are WRONG on purpose; cdna guide section 7 "ablate"): bits 16..19
+constexpr int VAR_QKIL = 1 << 20;         // QK^T: alternate the two key blocks (two independent accumulator chains)
+constexpr int VAR_PF8 = 1 << 21;          // QK^T: operand reads 8 deep instead of 4
+constexpr int ABL_NO_SOFTMAX = 1 << 16;   // P = bf16(S): no max, no exp, no row sum
+constexpr int ABL_NO_PV = 1 << 17;        // skip the PV MFMAs and V reads
+constexpr int ABL_NO_QK = 1 << 18;        // skip the QK^T MFMAs and K reads (S = stale registers)
+constexpr int ABL_NO_EXP = 1 << 19;       // softmax without the v_exp (p = fma result)
+constexpr int VAR_ALTPRIO = 32768; // s_setprio alternates between the wave halves every tile (with VAR_STAGE2: each half wins once per barrier)
+constexpr int VAR_DMA4 = 16384;    // only waves 0..NW/2-1 (the older half, which waits at the barrier anyway) issue the LDS-DMA
+constexpr int VAR_W4 = 8192;       // 4 waves x 64 rows, one wave per SIMD (fa3_fwd_w4_kernel.h)
 constexpr int VAR_YPRIO = 2048;    // static s_setprio 1 for the younger wave half (waves NW/2..NW-1)
 constexpr int VAR_LATEDMA = 4096;  // waves NW/2.. issue their DMA pieces after QK^T instead of at the top of the tile
 constexpr int VAR_STAGGER = 1024;  // waves 4-7 one phase behind waves 0-3 (fa3_fwd_stagger_kernel.h)
@@ -271,22 +281,24 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
     // XOR swizzle is applied to the per-lane SOURCE chunk (guide rule 21).  Wave w issues pieces w, w+8, ...
     // piece i covers LDS rows 4i..4i+3 (256 B each); lane l -> row 4i + (l>>4), stored chunk l&15.
     constexpr int PIECES = TILE_BYTES / 1024;            // 16 (D=128) or 8 (D=64)
-    constexpr int PPW = PIECES / NW;                     // pieces per wave
+    constexpr int NDW = (VAR & VAR_DMA4) ? NW / 2 : NW;  // waves that issue DMA
+    constexpr int PPW = PIECES / NDW;                    // pieces per issuing wave
     typedef __attribute__((address_space(1))) const char gchar;
     int dma_key[PPW];
     int dma_col;                                         // element offset of the source chunk in its key row
     {
-        const int R0 = 4 * wave + (lane >> 4);           // LDS row of piece `wave`
-        const int sw = ((R0 & 3) << 2) | ((R0 >> 2) & 3);   // rows 4*NW apart share the swizzle term (NW = 4, 8)
+        const int dw = wave % NDW;                       // issuing slot of this wave
+        const int R0 = 4 * dw + (lane >> 4);             // LDS row of piece `dw`
+        const int sw = ((R0 & 3) << 2) | ((R0 >> 2) & 3);   // rows 4*NDW apart share the swizzle term (NDW = 4, 8)
         const int cc = (lane & 15) ^ sw;                 // logical chunk stored at this lane's position
         if constexpr (D == 128) {
             dma_col = cc * 8;
 #pragma unroll
-            for (int t = 0; t < PPW; ++t) dma_key[t] = R0 + 4 * NW * t;
+            for (int t = 0; t < PPW; ++t) dma_key[t] = R0 + 4 * NDW * t;
         } else {
             dma_col = (cc & 7) * 8;
 #pragma unroll
-            for (int t = 0; t < PPW; ++t) dma_key[t] = 2 * (R0 + 4 * NW * t) + (cc >> 3);
+            for (int t = 0; t < PPW; ++t) dma_key[t] = 2 * (R0 + 4 * NDW * t) + (cc >> 3);
         }
     }
     // buffer-descriptor form: per-lane byte offsets are loop invariant, the tile steps the SRD base (SALU only)
@@ -300,6 +312,9 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
     const int64_t v_slab = ((int64_t)(p.Sk - 1) * p.v_ss + D) * 2;
     auto dma_tile = [&](auto bufc, int j) {
         constexpr int BUF = decltype(bufc)::value;
+        if constexpr (VAR & VAR_DMA4) {
+            if (wave >= NDW) return;   // wave-uniform: the other half never touches the address path
+        }
         if constexpr (VAR & VAR_BUFDMA) {
             const int64_t kstep = (int64_t)j * BLOCK_N * p.k_ss * 2, vstep = (int64_t)j * BLOCK_N * p.v_ss * 2;
             const srd_t ksrd = __builtin_amdgcn_make_buffer_rsrc(
@@ -308,7 +323,7 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
                 (void*)((const char*)vp + vstep), 0, (int)max((int64_t)0, v_slab - vstep), 0x00020000);
 #pragma unroll
             for (int t = 0; t < PPW; ++t) {
-                const uint32_t kd = smem_base + BUF * BUF_BYTES + (wave + NW * t) * 1024;
+                const uint32_t kd = smem_base + BUF * BUF_BYTES + (wave % NDW + NDW * t) * 1024;
                 lds_dma16_buf(ksrd, kvoff[t], kd);
                 lds_dma16_buf(vsrd, vvoff[t], kd + TILE_BYTES);
             }
@@ -363,6 +378,10 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
     // ---- one K/V tile: S^T = K Q^T, online softmax, O^T += V^T P^T -------------------------------------------
     auto compute_tile = [&](auto bufc, int key_base, int jnext = -1) {
         constexpr int BUF = decltype(bufc)::value;
+        if constexpr (VAR & VAR_ALTPRIO) {   // the half that lost the issue arbitration on the last tile wins this one
+            if (((wave >= NW / 2) ? 1 : 0) ^ ((key_base / BLOCK_N) & 1)) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         const lds_char* kimg = (const lds_char*)(uintptr_t)(BUF * BUF_BYTES);   // koff[]/voff[] carry the LDS base
         const lds_char* vimg = kimg + TILE_BYTES;
 
@@ -373,19 +392,25 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
-        constexpr int NQK = 2 * KS;
-        constexpr int PF = 4;
-        v8 afr[PF];
+        constexpr int NQK = (VAR & ABL_NO_QK) ? 0 : 2 * KS;
+        constexpr int PF = (VAR & ABL_NO_QK) ? 0 : ((VAR & VAR_PF8) ? 8 : 4);
+        v8 afr[8];
+        // step i -> (key block, k-step): blocked (kb = i / KS) or interleaved (kb = i & 1)
+        auto kb_of = [](int i) { return (VAR & VAR_QKIL) ? (i & 1) : (i / KS); };
+        auto ks_of = [](int i) { return (VAR & VAR_QKIL) ? (i >> 1) : (i % KS); };
 #pragma unroll
-        for (int i = 0; i < PF; ++i) afr[i] = *(const lds_v8*)(kimg + koff[i % KS] + (i / KS) * HALF_TILE);
+        for (int i = 0; i < PF; ++i) afr[i] = *(const lds_v8*)(kimg + koff[ks_of(i)] + kb_of(i) * HALF_TILE);
         if (VAR & VAR_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < NQK; ++i) {
-            s[i / KS] = E::mfma(afr[i % PF], qf[i % KS], s[i / KS]);
-            if (i + PF < NQK) afr[i % PF] = *(const lds_v8*)(kimg + koff[(i + PF) % KS] + ((i + PF) / KS) * HALF_TILE);
+            s[kb_of(i)] = E::mfma(afr[i % (PF ? PF : 1)], qf[ks_of(i)], s[kb_of(i)]);
+            if (i + PF < NQK) afr[i % (PF ? PF : 1)] = *(const lds_v8*)(kimg + koff[ks_of(i + PF)] + kb_of(i + PF) * HALF_TILE);
         }
         if (VAR & VAR_SETPRIO) __builtin_amdgcn_s_setprio(0);
-        if (VAR & VAR_SCHED) {
+        if constexpr (VAR & ABL_NO_QK) {
+            asm volatile("" : "+v"(s[0]), "+v"(s[1]));
+        }
+        if ((VAR & VAR_SCHED) && !(VAR & ABL_NO_QK)) {
             __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
 #pragma unroll
             for (int i = 0; i < NQK - PF; ++i) {
@@ -419,6 +444,7 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
                 }
         }
 
+        if constexpr (!(VAR & ABL_NO_SOFTMAX)) {
         // online softmax (flash_attention_3.py:239-246); a row lives in lanes (l, l^32)
         float mx = max3(s[0][0], s[1][0], s[0][1]);
         mx = max3(mx, s[1][1], s[0][2]);
@@ -449,14 +475,20 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
         float psum0 = 0.f, psum1 = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            s[0][e] = fast_exp2(__builtin_fmaf(s[0][e], c, -mc));
-            s[1][e] = fast_exp2(__builtin_fmaf(s[1][e], c, -mc));
+            if constexpr (VAR & ABL_NO_EXP) {
+                s[0][e] = __builtin_fmaf(s[0][e], c, -mc);
+                s[1][e] = __builtin_fmaf(s[1][e], c, -mc);
+            } else {
+                s[0][e] = fast_exp2(__builtin_fmaf(s[0][e], c, -mc));
+                s[1][e] = fast_exp2(__builtin_fmaf(s[1][e], c, -mc));
+            }
             if (!(VAR & VAR_LSUM)) {
                 psum0 += s[0][e];
                 psum1 += s[1][e];
             }
         }
         if (!(VAR & VAR_LSUM)) l_run += psum0 + psum1;
+        }   // !ABL_NO_SOFTMAX
 
         // O^T += V^T P^T
         if (VAR & VAR_SETPRIO) __builtin_amdgcn_s_setprio(1);
@@ -478,6 +510,10 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
                 }
                 constexpr int S2I = (D == 128) ? 0 : 1;
                 const int koffs = kb * HALF_TILE + ((D == 128) ? s2 * 16 * 256 : 0);
+                if constexpr (VAR & ABL_NO_PV) {
+                    asm volatile("" ::"v"(ph));
+                    continue;
+                }
 #pragma unroll
                 for (int db = 0; db < DB; ++db) {
                     const v4 lo = E::tr_read(vimg + voff[s2 * S2I][db][0] + koffs);

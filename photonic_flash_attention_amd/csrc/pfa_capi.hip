@@ -37,6 +37,10 @@ Variant mk(const char* tn, const char* on) {
     if (VAR & pfa::VAR_STAGGER) v.lds_bytes = 5 * pfa::BLOCK_N * D * 2;   // K ring 2 + V ring 3
     v.nthreads = ((VAR & pfa::VAR_NW4) ? 4 : 8) * 64;
     v.block_m = v.nthreads / 2;
+    if (VAR & pfa::VAR_W4) {
+        v.nthreads = 256;
+        v.block_m = 256;
+    }
     return v;
 }
 
@@ -86,6 +90,21 @@ Variant pick(const pfa_fa3_args* a) {
             case 8: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_PIPE | pfa::VAR_SCHED>(causal);        // half-tile software pipeline
             case 9: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_STAGGER>(causal);                      // staggered wave halves
             case 16: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_STAMP>(causal);                         // diagnostic stamps
+            case 10: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_DMA4>(causal);                          // older wave half issues all DMA
+            case 11: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_STAGE2 | pfa::VAR_ALTPRIO>(causal);     // alternate priority, barrier per 2 tiles
+            case 12: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_STAGE2 | pfa::VAR_ALTPRIO | pfa::VAR_DMA4>(causal);
+            case 13: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_ALTPRIO>(causal);
+            case 14: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_QKIL>(causal);
+            case 15: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_PF8>(causal);
+            case 17: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_QKIL | pfa::VAR_PF8>(causal);
+            case 26: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV | pfa::VAR_QKIL>(causal);
+            case 27: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV | pfa::VAR_PF8>(causal);
+            case 20: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX>(causal);
+            case 21: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_PV>(causal);
+            case 22: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_QK>(causal);
+            case 23: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_EXP>(causal);
+            case 24: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV>(causal);
+            case 25: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_QK>(causal);
             default: break;
         }
     }
