@@ -124,6 +124,14 @@ constexpr int VAR_DEFER_MAX = 1;   // T13: rescale O only when a row max grew by
 constexpr int VAR_SETPRIO = 2;     // s_setprio(1) around the MFMA clusters
 constexpr int VAR_SCHED = 4;       // pin the QK^T read/MFMA interleave with sched_group_barrier
 // timing-only ablations (results are WRONG on purpose; cdna guide section 7 "ablate"): bits 16..19
+constexpr int ABL_NO_DMA = 1 << 23;       // never refill LDS after the prologue (stale K/V tiles)
+constexpr int ABL_NO_BARRIER = 1 << 24;   // no per-tile barrier
+constexpr int VAR_XCDG2 = 1 << 28;        // block order: per XCD, heads in groups of 2 (all Q blocks of a group run together)
+constexpr int VAR_XCDG4 = 1 << 29;        // ... groups of 4
+constexpr int ABL_AGPR_ACC = 1 << 27;     // QK^T accumulators forced into the accumulator half (inline-asm MFMA, "+a")
+constexpr int ABL_NO_MFMA = 1 << 26;      // QK^T: LDS reads only (operands consumed by an empty asm)
+constexpr int ABL_NO_LDS = 1 << 25;       // QK^T A operands from registers instead of LDS
+constexpr int VAR_RING3 = 1 << 22;        // 3-slot K/V ring: DMA for tile j+2 issued at the END of tile j (before the barrier wait)
 constexpr int VAR_QKIL = 1 << 20;         // QK^T: alternate the two key blocks (two independent accumulator chains)
 constexpr int VAR_PF8 = 1 << 21;          // QK^T: operand reads 8 deep instead of 4
 constexpr int ABL_NO_SOFTMAX = 1 << 16;   // P = bf16(S): no max, no exp, no row sum
@@ -215,8 +223,22 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
     // ---- block -> (q block, batch*head): heaviest (longest causal row) blocks first ----------------
     const int BH = p.B * p.H;
     const int n = blockIdx.x;
-    const int qrank = n / BH;
-    const int bh = n - qrank * BH;
+    int qrank = n / BH;
+    int bh = n - qrank * BH;
+    if constexpr ((VAR & VAR_XCDG2) || (VAR & VAR_XCDG4)) {
+        // blocks n, n+8, ... share an XCD (round-robin dispatch; speed only).  Within an XCD walk the heads in
+        // groups of G so that the ~32 resident workgroups are G heads x many Q blocks: every K/V tile is then
+        // fetched into that XCD's L2 once and re-read by the other Q blocks of the head while it is still there.
+        constexpr int G = (VAR & VAR_XCDG2) ? 2 : 4;
+        const int hpx = BH / 8;                       // heads per XCD
+        if ((BH % 8) == 0 && (hpx % G) == 0) {
+            const int xcd = n & 7, idx = n >> 3;
+            const int per_group = p.nqblk * G;
+            const int g = idx / per_group, within = idx - g * per_group;
+            qrank = within / G;
+            bh = xcd + 8 * (g * G + (within - qrank * G));
+        }
+    }
     const int qblk = CAUSAL ? (p.nqblk - 1 - qrank) : qrank;
     const int b = bh / p.H;
     const int hh = bh - b * p.H;
@@ -388,10 +410,12 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
         // S^T = K Q^T: 16 MFMAs (2 key blocks x KS k-steps), A fragments prefetched PF deep from LDS so the
         // ds_read latency hides behind the MFMAs already issued (hipcc otherwise emits read -> wait -> mfma)
         f32x16 s[2];
+        if constexpr (!(VAR & ABL_AGPR_ACC)) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+        }
         constexpr int NQK = (VAR & ABL_NO_QK) ? 0 : 2 * KS;
         constexpr int PF = (VAR & ABL_NO_QK) ? 0 : ((VAR & VAR_PF8) ? 8 : 4);
         v8 afr[8];
@@ -403,14 +427,27 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
         if (VAR & VAR_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < NQK; ++i) {
-            s[kb_of(i)] = E::mfma(afr[i % (PF ? PF : 1)], qf[ks_of(i)], s[kb_of(i)]);
-            if (i + PF < NQK) afr[i % (PF ? PF : 1)] = *(const lds_v8*)(kimg + koff[ks_of(i + PF)] + kb_of(i + PF) * HALF_TILE);
+            if constexpr (VAR & ABL_NO_LDS) {
+                s[kb_of(i)] = E::mfma(qf[(ks_of(i) + 1) % KS], qf[ks_of(i)], s[kb_of(i)]);
+            } else if constexpr (VAR & ABL_AGPR_ACC) {
+                if (ks_of(i) == 0)
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=a"(s[kb_of(i)]) : "v"(afr[i % PF]), "v"(qf[ks_of(i)]));
+                else
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(s[kb_of(i)]) : "v"(afr[i % PF]), "v"(qf[ks_of(i)]));
+                if (i + PF < NQK) afr[i % PF] = *(const lds_v8*)(kimg + koff[ks_of(i + PF)] + kb_of(i + PF) * HALF_TILE);
+            } else if constexpr (VAR & ABL_NO_MFMA) {
+                asm volatile("" ::"v"(afr[i % PF]));
+                if (i + PF < NQK) afr[i % PF] = *(const lds_v8*)(kimg + koff[ks_of(i + PF)] + kb_of(i + PF) * HALF_TILE);
+            } else {
+                s[kb_of(i)] = E::mfma(afr[i % (PF ? PF : 1)], qf[ks_of(i)], s[kb_of(i)]);
+                if (i + PF < NQK) afr[i % (PF ? PF : 1)] = *(const lds_v8*)(kimg + koff[ks_of(i + PF)] + kb_of(i + PF) * HALF_TILE);
+            }
         }
         if (VAR & VAR_SETPRIO) __builtin_amdgcn_s_setprio(0);
         if constexpr (VAR & ABL_NO_QK) {
             asm volatile("" : "+v"(s[0]), "+v"(s[1]));
         }
-        if ((VAR & VAR_SCHED) && !(VAR & ABL_NO_QK)) {
+        if ((VAR & VAR_SCHED) && !(VAR & ABL_NO_QK) && !(VAR & ABL_NO_LDS) && !(VAR & ABL_NO_MFMA) && !(VAR & ABL_AGPR_ACC)) {
             __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
 #pragma unroll
             for (int i = 0; i < NQK - PF; ++i) {
@@ -420,6 +457,10 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
             __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
         }
 
+        if constexpr (VAR & ABL_AGPR_ACC) {   // timing only: consume the accumulators where they are and stop
+            asm volatile("s_nop 15\n\ts_nop 15" ::"a"(s[0]), "a"(s[1]));
+            return;
+        }
         if constexpr (VAR & VAR_LATEDMA) {
             if (jnext >= 0) dma_tile(IC<BUF ^ 1>{}, jnext);   // late issue (younger half): off the post-barrier rush
         }
@@ -532,6 +573,12 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
     };
 
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // VAR_STAMP: dma issue | compute | vmcnt wait | barrier | tiles
+    unsigned long long st_t0 = 0, st_r0 = 0;
+    if constexpr (VAR & VAR_STAMP) {   // shader clock vs the constant 100 MHz counter -> in-kernel clock (guide, DVFS item 6)
+        st_t0 = __builtin_amdgcn_s_memtime();
+        st_r0 = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
     unsigned long long st_qk = 0;
     auto step = [&](auto bufc, int j) {
         constexpr int BUF = decltype(bufc)::value;
@@ -556,11 +603,13 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_s_barrier();
         } else if constexpr (VAR & VAR_GLDS) {
-            if (j + 1 < nt) dma_tile(IC<BUF ^ 1>{}, j + 1);   // lands in the other buffer under this tile's math
+            if constexpr (!(VAR & ABL_NO_DMA)) {
+                if (j + 1 < nt) dma_tile(IC<BUF ^ 1>{}, j + 1);   // lands in the other buffer under this tile's math
+            }
             if (j * BLOCK_N < wave_kv_end) compute_tile(bufc, j * BLOCK_N);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed ...
             __builtin_amdgcn_s_waitcnt(0xC07F);               // (lgkmcnt(0): this wave's LDS reads are done)
-            __builtin_amdgcn_s_barrier();                     // ... and so have everybody else's
+            if constexpr (!(VAR & ABL_NO_BARRIER)) __builtin_amdgcn_s_barrier();   // ... and so have everybody else's
         } else {
             if (j + 1 < nt) load_tile(j + 1);              // HBM latency hides under this tile's math
             if (j * BLOCK_N < wave_kv_end) compute_tile(bufc, j * BLOCK_N);   // wave-uniform causal skip
@@ -572,7 +621,7 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
     if (nt > 0) {
         if constexpr (VAR & VAR_GLDS) {
             dma_tile(IC<0>{}, 0);
-            if constexpr (VAR & VAR_STAGE2) {
+            if constexpr ((VAR & VAR_STAGE2) || (VAR & VAR_RING3)) {
                 if (nt > 1) dma_tile(IC<1>{}, 1);
             }
         } else {
@@ -589,7 +638,32 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if constexpr (VAR & VAR_STAGE2) {
+    if constexpr (VAR & VAR_RING3) {
+        // Waves reach the end of a tile at different times (the older half of each SIMD pair ~700 cycles early):
+        // issuing there spreads the 32 DMA pieces of a tile over time instead of queueing all of them on the CU's
+        // address path right after the barrier, and the early waves pay the issue latency out of their barrier wait.
+        static_assert((VAR & VAR_GLDS) != 0, "VAR_RING3 needs the LDS-DMA path");
+        auto ring_step = [&](auto slotc, int j) {
+            constexpr int SLOT = decltype(slotc)::value;
+            if (j * BLOCK_N < wave_kv_end) compute_tile(slotc, j * BLOCK_N);
+            if (j + 2 < nt) {
+                dma_tile(IC<(SLOT + 2) % 3>{}, j + 2);
+                // tile j+1 (issued one tile ago) must have landed; tile j+2's 2*PPW pieces may stay in flight
+                if constexpr (2 * PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if constexpr (2 * PPW == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+        };
+        for (int j = 0; j < nt; j += 3) {
+            ring_step(IC<0>{}, j);
+            if (j + 1 < nt) ring_step(IC<1>{}, j + 1);
+            if (j + 2 < nt) ring_step(IC<2>{}, j + 2);
+        }
+    } else if constexpr (VAR & VAR_STAGE2) {
         // stage = two tiles in LDS slots {2P, 2P+1}; one barrier per stage
         static_assert((VAR & VAR_GLDS) != 0, "VAR_STAGE2 needs the LDS-DMA path");
         auto stage = [&](auto pc, int js) {
@@ -616,6 +690,9 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
     }
 
     if constexpr (VAR & VAR_STAMP) {
+        st_acc[6] = __builtin_amdgcn_s_memtime() - st_t0;
+        st_acc[7] = __builtin_amdgcn_s_memrealtime() - st_r0;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
         if (lane == 0 && p.dbg) {
             unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
 #pragma unroll

@@ -34,6 +34,7 @@ Variant mk(const char* tn, const char* on) {
     snprintf(v.name, sizeof(v.name), "fa3_fwd_%s_d%d_%s%s%s_%s_v%d", tn, D, C ? "causal" : "full", S ? "_splitp" : "",
              K ? "_kmask" : "", on, VAR);
     v.lds_bytes = ((VAR & pfa::VAR_STAGE2) ? 4 : 2) * 2 * pfa::BLOCK_N * D * 2;
+    if (VAR & pfa::VAR_RING3) v.lds_bytes = 3 * 2 * pfa::BLOCK_N * D * 2;
     if (VAR & pfa::VAR_STAGGER) v.lds_bytes = 5 * pfa::BLOCK_N * D * 2;   // K ring 2 + V ring 3
     v.nthreads = ((VAR & pfa::VAR_NW4) ? 4 : 8) * 64;
     v.block_m = v.nthreads / 2;
@@ -94,6 +95,17 @@ Variant pick(const pfa_fa3_args* a) {
             case 11: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_STAGE2 | pfa::VAR_ALTPRIO>(causal);     // alternate priority, barrier per 2 tiles
             case 12: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_STAGE2 | pfa::VAR_ALTPRIO | pfa::VAR_DMA4>(causal);
             case 13: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_ALTPRIO>(causal);
+            case 18: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_RING3>(causal);
+            case 19: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_RING3 | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV>(causal);
+            case 28: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV | pfa::ABL_NO_DMA>(causal);
+            case 29: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV | pfa::ABL_NO_DMA | pfa::ABL_NO_BARRIER>(causal);
+            case 30: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV | pfa::ABL_NO_DMA | pfa::ABL_NO_BARRIER | pfa::ABL_NO_LDS>(causal);
+            case 33: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV | pfa::ABL_NO_DMA | pfa::ABL_NO_BARRIER | pfa::ABL_NO_MFMA>(causal);
+            case 34: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV | pfa::ABL_NO_DMA | pfa::ABL_NO_BARRIER | pfa::ABL_AGPR_ACC>(causal);
+            case 35: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_XCDG2>(causal);
+            case 36: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_XCDG4>(causal);
+            case 31: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_DMA>(causal);
+            case 32: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_DMA | pfa::ABL_NO_BARRIER>(causal);
             case 14: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_QKIL>(causal);
             case 15: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_PF8>(causal);
             case 17: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_QKIL | pfa::VAR_PF8>(causal);

@@ -11,7 +11,7 @@ nwg = B * H * (S // 256)
 dbg = torch.zeros(nwg * 8 * 8, dtype=torch.int64, device=dev)
 args, keep = ops.build_args(q, k, v, out, causal=causal, variant=16)
 args.workspace = dbg.data_ptr(); args.workspace_bytes = dbg.numel() * 8
-for _ in range(3):
+for _ in range(int(os.environ.get("STAMP_ITERS", "600"))):   # long enough to be in the steady DVFS state
     st = _capi.load().pfa_fa3_fwd(C.byref(args), C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert st == 0, st
 torch.cuda.synchronize()
@@ -22,6 +22,9 @@ tot = d[..., :4].sum()
 print(f"{'causal' if causal else 'full'}: {int(tiles)} wave-tiles, {tot / tiles:.0f} cycles per wave-tile (stamps add ~40 cyc each)")
 for i in (0, 1, 5, 2, 3):
     print(f"  {names[i]:28s} {d[..., i].sum() / tiles:8.0f} cyc/tile  {100 * d[..., i].sum() / tot:5.1f} %")
+clk = (d[..., 6] / d[..., 7].clamp(min=1) * 100.0)
+print(f"  in-kernel shader clock (s_memtime / s_memrealtime x 100 MHz): median {clk.median():.0f} MHz, "
+      f"min {clk.min():.0f}, max {clk.max():.0f}")
 w = d[..., :4].sum(-1) / d[..., 4].clamp(min=1)
 print("  per-wave cycles/tile by wave id:", [f"{w[:, i].mean():.0f}" for i in range(8)])
 for i in (1, 3):
