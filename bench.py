@@ -35,6 +35,13 @@ if REPO not in sys.path:
 
 MFMA_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level table)
 
+# HBM-side bytes per launch from the PMC passes of tools/profile.sh (separate rocprofv3 --pmc runs; FETCH_SIZE x 2
+# per the gfx950 wide-load correction of MI355X_MICROARCH.md section HBM, + WRITE_SIZE).  Not measurable from inside
+# this process, so the committed profile is quoted, keyed by workload; null for anything not profiled.
+PMC_TRAFFIC_BYTES = {
+    "C3": (542.2e6, "profiles/r01_v2_C3_rocprof_summary.md: FETCH_SIZE 231875 KB x 2 + WRITE_SIZE 65817 KB"),
+}
+
 WORKLOADS = {
     # name: (B per GPU, H, S, D, causal)
     "C3": (4, 16, 4096, 128, True),     # headline: BASELINE.json configs[2]
@@ -206,7 +213,10 @@ def main():
                        "sharding": f"batch x head over {world} rank(s), no data-path collective",
                        "flop_convention": "4*B*H*S*S*D, halved for causal", "kernel": name, "workgroups": nwg},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                         "traffic": PMC_TRAFFIC_BYTES.get(args.workload, (None, None))[0],
+                         "traffic_source": PMC_TRAFFIC_BYTES.get(args.workload, (None, None))[1],
+                         "algorithmic_bytes": 2 * 2 * 2 * B * H * S * D,
                          "kernel_ms": round(float(kmax), 4),
                          "hbm_algorithmic_GBps": round(2 * 2 * 2 * B * H * S * D / (float(kmax) * 1e-3) / 1e9, 1)},
         }

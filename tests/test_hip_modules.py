@@ -179,3 +179,20 @@ def test_no_grad_required_and_dropout_rules():
     m.eval()
     with torch.no_grad():
         assert m(x)[0].shape == x.shape                               # dropout is a no-op in eval (:174-175)
+
+
+def test_cli_benchmark_schema(tmp_path):
+    """Counterpart of the reference's `photonic-benchmark` (cli.py:20-145): same flags, same result keys."""
+    import json
+    from photonic_flash_attention_amd import cli
+    out = tmp_path / "bench.json"
+    args = cli._parser().parse_args(["--seq-lengths", "128", "640", "--batch-sizes", "2", "--embed-dim", "256",
+                                     "--num-heads", "4", "--num-iterations", "3", "--output", str(out)])
+    res = cli.benchmark(args)
+    ref_keys = {"batch_size", "seq_length", "embed_dim", "num_heads", "avg_latency_ms", "std_latency_ms",
+                "min_latency_ms", "max_latency_ms", "tokens_per_sec", "last_device_used", "gpu_calls",
+                "photonic_calls", "photonic_usage_ratio"}
+    assert len(res) == 2 and all(ref_keys <= set(r) for r in res)
+    assert all(r["last_device_used"] == "gpu" and r["attn_tflops"] > 0 for r in res)
+    data = json.loads(out.read_text())
+    assert set(data) == {"benchmark_info", "results"} and {"version", "timestamp", "device_info", "config"} <= set(data["benchmark_info"])
