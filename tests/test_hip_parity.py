@@ -184,3 +184,47 @@ def test_bad_arguments_raise_before_launch():
     qc = torch.zeros(1, 2, 16, 64, dtype=torch.bfloat16)
     with pytest.raises(ValueError):
         ops.fa3_forward(qc, qc, qc)                   # host tensors: no CPU path
+
+
+def test_reentrant_from_threads_on_side_streams():
+    """SURVEY.md section 5 (race row): the reference calls the electronic branch from a thread pool
+    (hybrid_router.py:323,461-463) and its concurrency test uses 8 caller threads; the C ABI must be
+    re-entrant and honour the caller's stream."""
+    import threading
+    from photonic_flash_attention_amd import ops, synth
+    dev = _dev()
+    q, k, v = (t.to(dev) for t in synth.qkv(2, 4, 512, 512, 64, 404, "bf16"))
+    want, _ = ops.fa3_forward_bshd(q, k, v, causal=True)
+    torch.cuda.synchronize()
+    outs, errs = [None] * 8, []
+
+    def work(i):
+        try:
+            s = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(s):
+                for _ in range(20):
+                    o, _ = ops.fa3_forward_bshd(q, k, v, causal=True)
+                s.synchronize()
+            outs[i] = o
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs
+    assert all(torch.equal(o, want) for o in outs)
+
+
+def test_runs_to_run_determinism_and_variant_equivalence():
+    """Bitwise reproducibility of the production kernel, and the development schedules (register staging,
+    LDS-DMA, staggered wave halves, 3-slot ring ...) compute bit-identical results."""
+    from photonic_flash_attention_amd import ops, synth
+    dev = _dev()
+    q, k, v = (t.to(dev) for t in synth.qkv(1, 4, 1536, 1536, 128, 505, "bf16"))
+    base, _ = ops.fa3_forward_bshd(q, k, v, causal=True)
+    again, _ = ops.fa3_forward_bshd(q, k, v, causal=True)
+    assert torch.equal(base, again)
+    for var in (2, 3, 4, 6, 9, 10, 11, 12, 18, 35):
+        o, _ = ops.fa3_forward_bshd(q, k, v, causal=True, _variant=var)
+        assert torch.equal(o, base), f"variant {var}"
