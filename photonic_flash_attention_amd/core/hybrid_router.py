@@ -41,6 +41,7 @@ from .flash_attention_3 import FlashAttention3
 
 @dataclass
 class PerformanceMetrics:
+    """One measurement fed to the router (field names as in the reference, hybrid_router.py:20-29)."""
     latency_ms: float = 0.0
     throughput_tokens_per_sec: float = 0.0
     energy_mj: float = 0.0
@@ -50,8 +51,12 @@ class PerformanceMetrics:
     timestamp: float = field(default_factory=time.time)
 
 
+_DTYPE_FEATURE = {torch.float32: 1.0, torch.float16: 0.5}
+
+
 @dataclass
 class WorkloadCharacteristics:
+    """Shape/dtype summary of a request; ``to_features`` is the 7-vector of the reference (:42-52)."""
     batch_size: int
     seq_length: int
     embed_dim: int
@@ -61,9 +66,8 @@ class WorkloadCharacteristics:
     dtype: torch.dtype = torch.float32
 
     def to_features(self) -> np.ndarray:
-        prec = 1.0 if self.dtype == torch.float32 else 0.5 if self.dtype == torch.float16 else 0.25
-        return np.array([self.batch_size, self.seq_length, self.embed_dim, self.num_heads,
-                         float(self.is_training), float(self.has_mask), prec], dtype=np.float64)
+        return np.asarray([self.batch_size, self.seq_length, self.embed_dim, self.num_heads, self.is_training,
+                           self.has_mask, _DTYPE_FEATURE.get(self.dtype, 0.25)], dtype=np.float64)
 
 
 class AdaptiveRouter:
@@ -123,17 +127,12 @@ class AdaptiveRouter:
 
     def get_stats(self) -> Dict[str, Any]:
         with self._lock:
-            total = self._cache_hits + self._cache_misses
-            return {
-                "gpu_samples": len(self.gpu_history),
-                "photonic_samples": 0,
-                "total_samples": len(self.gpu_history),
-                "cache_size": len(self._prediction_cache),
-                "cache_hit_rate": self._cache_hits / total if total else 0.0,
-                "exploration_rate": self.exploration_rate,
-                "min_samples_for_ml": self.min_samples_for_prediction,
-                "using_ml_prediction": False,
-            }
+            lookups = self._cache_hits + self._cache_misses
+            n = len(self.gpu_history)
+            return dict(gpu_samples=n, photonic_samples=0, total_samples=n, cache_size=len(self._prediction_cache),
+                        cache_hit_rate=(self._cache_hits / lookups) if lookups else 0.0,
+                        exploration_rate=self.exploration_rate, min_samples_for_ml=self.min_samples_for_prediction,
+                        using_ml_prediction=False)
 
 
 class HybridFlashAttention(nn.Module):
@@ -234,17 +233,11 @@ class HybridFlashAttention(nn.Module):
         return elements * (4 if workload.dtype == torch.float32 else 2) / (1024 * 1024)
 
     def get_performance_stats(self) -> Dict[str, Any]:
-        stats = {
-            "total_requests": self.total_requests,
-            "concurrent_requests": self.concurrent_requests,
-            "peak_concurrent": self.peak_concurrent,
-            "warmup_complete": self.warmup_complete,
-            "scaling_enabled": self.enable_scaling,
-            "max_concurrent": self.max_concurrent_requests,
-        }
-        stats.update(self.router.get_stats())
-        stats["gpu_stats"] = self.gpu_attention.get_performance_stats()
-        return stats
+        """Request counters + router counters + the core's stats (keys of the reference, :619-637)."""
+        return dict(total_requests=self.total_requests, concurrent_requests=self.concurrent_requests,
+                    peak_concurrent=self.peak_concurrent, warmup_complete=self.warmup_complete,
+                    scaling_enabled=self.enable_scaling, max_concurrent=self.max_concurrent_requests,
+                    **self.router.get_stats(), gpu_stats=self.gpu_attention.get_performance_stats())
 
     def enable_auto_scaling(self, enabled: bool = True, max_concurrent: Optional[int] = None) -> None:
         self.enable_scaling = enabled
