@@ -11,12 +11,13 @@ import torch as _torch
 from .config import GlobalConfig, get_config
 from .core.flash_attention_3 import FlashAttention3
 from .core.hybrid_router import AdaptiveRouter, HybridFlashAttention
+from .integration.pytorch.convert import convert_to_photonic
 from .integration.pytorch.modules import PhotonicFlashAttention, PhotonicMultiHeadAttention
 from .ops import fa3_forward, fa3_forward_bshd, is_available
 
 __version__ = "0.1.0"
 __all__ = ["PhotonicFlashAttention", "PhotonicMultiHeadAttention", "FlashAttention3", "HybridFlashAttention",
-           "AdaptiveRouter", "fa3_forward", "fa3_forward_bshd", "is_available", "get_config", "GlobalConfig",
+           "AdaptiveRouter", "convert_to_photonic", "fa3_forward", "fa3_forward_bshd", "is_available", "get_config", "GlobalConfig",
            "get_version", "get_device_info", "set_global_config"]
 
 

@@ -128,6 +128,7 @@ constexpr int ABL_NO_DMA = 1 << 23;       // never refill LDS after the prologue
 constexpr int ABL_NO_BARRIER = 1 << 24;   // no per-tile barrier
 constexpr int VAR_XCDG2 = 1 << 28;        // block order: per XCD, heads in groups of 2 (all Q blocks of a group run together)
 constexpr int VAR_XCDG4 = 1 << 29;        // ... groups of 4
+constexpr int ABL_AGPR_OPND = 1 << 30;    // QK^T: LDS fragments land in AGPRs (asm ds_read "=a"), MFMA A operand from AGPR
 constexpr int ABL_AGPR_ACC = 1 << 27;     // QK^T accumulators forced into the accumulator half (inline-asm MFMA, "+a")
 constexpr int ABL_NO_MFMA = 1 << 26;      // QK^T: LDS reads only (operands consumed by an empty asm)
 constexpr int ABL_NO_LDS = 1 << 25;       // QK^T A operands from registers instead of LDS
@@ -422,6 +423,25 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
         // step i -> (key block, k-step): blocked (kb = i / KS) or interleaved (kb = i & 1)
         auto kb_of = [](int i) { return (VAR & VAR_QKIL) ? (i & 1) : (i / KS); };
         auto ks_of = [](int i) { return (VAR & VAR_QKIL) ? (i >> 1) : (i % KS); };
+        if constexpr (VAR & ABL_AGPR_OPND) {
+            // timing experiment: does the LDS->register stream overlap the MFMAs when it lands in the accumulator half?
+            auto rd = [&](int i, v8& dst) {
+                const uint32_t addr = koff[ks_of(i)] + BUF * BUF_BYTES + kb_of(i) * HALF_TILE;
+                asm volatile("ds_read_b128 %0, %1" : "=a"(dst) : "v"(addr));
+            };
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rd(i, afr[i]);
+#pragma unroll
+            for (int i = 0; i < 2 * KS; ++i) {
+                const int left = (2 * KS - 1 - i) < 3 ? (2 * KS - 1 - i) : 3;
+                if (left == 3) asm volatile("s_waitcnt lgkmcnt(3)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s[kb_of(i)]) : "a"(afr[i % 4]), "v"(qf[ks_of(i)]));
+                else if (left == 2) asm volatile("s_waitcnt lgkmcnt(2)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s[kb_of(i)]) : "a"(afr[i % 4]), "v"(qf[ks_of(i)]));
+                else if (left == 1) asm volatile("s_waitcnt lgkmcnt(1)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s[kb_of(i)]) : "a"(afr[i % 4]), "v"(qf[ks_of(i)]));
+                else asm volatile("s_waitcnt lgkmcnt(0)\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s[kb_of(i)]) : "a"(afr[i % 4]), "v"(qf[ks_of(i)]));
+                if (i + 4 < 2 * KS) rd(i + 4, afr[i % 4]);
+            }
+            asm volatile("s_nop 15\n\ts_nop 15" : "+v"(s[0]), "+v"(s[1]));
+        } else {
 #pragma unroll
         for (int i = 0; i < PF; ++i) afr[i] = *(const lds_v8*)(kimg + koff[ks_of(i)] + kb_of(i) * HALF_TILE);
         if (VAR & VAR_SETPRIO) __builtin_amdgcn_s_setprio(1);
@@ -442,6 +462,7 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
                 s[kb_of(i)] = E::mfma(afr[i % (PF ? PF : 1)], qf[ks_of(i)], s[kb_of(i)]);
                 if (i + PF < NQK) afr[i % (PF ? PF : 1)] = *(const lds_v8*)(kimg + koff[ks_of(i + PF)] + kb_of(i + PF) * HALF_TILE);
             }
+        }
         }
         if (VAR & VAR_SETPRIO) __builtin_amdgcn_s_setprio(0);
         if constexpr (VAR & ABL_NO_QK) {

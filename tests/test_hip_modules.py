@@ -196,3 +196,27 @@ def test_cli_benchmark_schema(tmp_path):
     assert all(r["last_device_used"] == "gpu" and r["attn_tflops"] > 0 for r in res)
     data = json.loads(out.read_text())
     assert set(data) == {"benchmark_info", "results"} and {"version", "timestamp", "device_info", "config"} <= set(data["benchmark_info"])
+
+
+def test_convert_to_photonic_transformer_layer_on_gpu():
+    """Converted nn.TransformerEncoderLayer (bf16, our kernel) vs the ORIGINAL torch layer in fp32 on the CPU."""
+    import torch.nn as nn
+    from photonic_flash_attention_amd import convert_to_photonic
+    torch.manual_seed(1)
+    layer = nn.TransformerEncoderLayer(d_model=512, nhead=4, dim_feedforward=1024, dropout=0.0, batch_first=True).eval()
+    x = torch.from_numpy(synth.normal_f32((2, 300, 512), 21))
+    pad = torch.zeros(2, 300, dtype=torch.bool)
+    pad[1, 250:] = True
+    causal = nn.Transformer.generate_square_subsequent_mask(300)
+    conv, rep = convert_to_photonic(layer, dtype=torch.bfloat16)
+    assert rep.converted_layers == ["self_attn"]
+    conv = conv.to(DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        for kw in (dict(), dict(src_key_padding_mask=pad), dict(src_mask=causal, is_causal=True)):
+            want = layer(x, **kw)
+            kw_dev = {k_: (v_.to(DEV) if torch.is_tensor(v_) else v_) for k_, v_ in kw.items()}
+            got = conv(x.to(DEV, torch.bfloat16), **kw_dev).float().cpu()
+            keep = ~pad if "src_key_padding_mask" in kw else torch.ones(2, 300, dtype=torch.bool)
+            err = float((got - want)[keep].abs().max())
+            assert err <= 0.12, (list(kw), err)            # bf16 end-to-end layer (LayerNorm + FFN in bf16)
+            assert float((got - want)[keep].abs().mean()) <= 0.012

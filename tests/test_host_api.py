@@ -229,3 +229,35 @@ def test_global_config_env_and_update(monkeypatch):
     with pytest.raises(ValueError):
         set_global_config(no_such_key=1)
     GlobalConfig.reset()
+
+
+def test_convert_to_photonic_replaces_torch_mha(monkeypatch):
+    """model conversion for local nn.Module objects (reference convert.py:441-452
+    weight rule).  Core replaced by the oracle double; checks weight mapping + PyTorch mask dialect translation
+    against the ORIGINAL torch layer."""
+    import torch.nn as nn
+    from photonic_flash_attention_amd import FlashAttention3
+    from photonic_flash_attention_amd.integration.pytorch.convert import TorchMHAReplacement, convert_to_photonic
+    monkeypatch.setattr(FlashAttention3, "_flash_attention_forward", _oracle_core)
+    torch.manual_seed(0)
+    layer = nn.TransformerEncoderLayer(d_model=256, nhead=4, dim_feedforward=512, dropout=0.0, batch_first=True).eval()
+    conv, rep = convert_to_photonic(layer)
+    assert rep.converted_layers == ["self_attn"] and not rep.skipped_layers and not rep.conversion_errors
+    assert isinstance(conv.self_attn, TorchMHAReplacement) and isinstance(layer.self_attn, nn.MultiheadAttention)
+    x = torch.from_numpy(synth.normal_f32((2, 50, 256), 8))
+    pad = torch.zeros(2, 50, dtype=torch.bool)
+    pad[0, 40:] = True                                               # PyTorch convention: True = ignore
+    causal = nn.Transformer.generate_square_subsequent_mask(50)
+    with torch.no_grad():
+        for kw in (dict(), dict(src_key_padding_mask=pad), dict(src_mask=causal, is_causal=True),
+                   dict(src_mask=causal), dict(src_mask=causal, src_key_padding_mask=pad)):
+            want = layer(x, **kw)
+            got = conv(x, **kw)
+            keep = ~pad if "src_key_padding_mask" in kw else torch.ones(2, 50, dtype=torch.bool)
+            assert float((got - want)[keep].abs().max()) <= 2e-5, kw
+    # skipped layers are reported, strings are refused
+    odd = nn.MultiheadAttention(96, 4)                               # head_dim 24: no kernel
+    _, rep2 = convert_to_photonic(nn.Sequential(odd))
+    assert rep2.skipped_layers == ["0"] and "head_dim" in rep2.compatibility_warnings[0]
+    with pytest.raises(ValueError):
+        convert_to_photonic("bert-base-uncased")
