@@ -418,8 +418,9 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
             for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
         }
         constexpr int NQK = (VAR & ABL_NO_QK) ? 0 : 2 * KS;
-        constexpr int PF = (VAR & ABL_NO_QK) ? 0 : ((VAR & VAR_PF8) ? 8 : 4);
-        v8 afr[8];
+        // VAR_PF8 alone: 8 deep; VAR_PF8 + VAR_SETPRIO: all 2*KS fragments first ("load cluster, then MFMA cluster")
+        constexpr int PF = (VAR & ABL_NO_QK) ? 0 : ((VAR & VAR_PF8) ? ((VAR & VAR_SETPRIO) ? 2 * KS : 8) : 4);
+        v8 afr[2 * KS];
         // step i -> (key block, k-step): blocked (kb = i / KS) or interleaved (kb = i & 1)
         auto kb_of = [](int i) { return (VAR & VAR_QKIL) ? (i & 1) : (i / KS); };
         auto ks_of = [](int i) { return (VAR & VAR_QKIL) ? (i >> 1) : (i % KS); };
@@ -468,7 +469,8 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
         if constexpr (VAR & ABL_NO_QK) {
             asm volatile("" : "+v"(s[0]), "+v"(s[1]));
         }
-        if ((VAR & VAR_SCHED) && !(VAR & ABL_NO_QK) && !(VAR & ABL_NO_LDS) && !(VAR & ABL_NO_MFMA) && !(VAR & ABL_AGPR_ACC)) {
+        if ((VAR & VAR_SCHED) && !(VAR & ABL_NO_QK) && !(VAR & ABL_NO_LDS) && !(VAR & ABL_NO_MFMA) && !(VAR & ABL_AGPR_ACC) &&
+            !(VAR & ABL_AGPR_OPND)) {
             __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
 #pragma unroll
             for (int i = 0; i < NQK - PF; ++i) {

@@ -105,6 +105,8 @@ Variant pick(const pfa_fa3_args* a) {
             case 35: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_XCDG2>(causal);
             case 36: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_XCDG4>(causal);
             case 37: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV | pfa::ABL_NO_DMA | pfa::ABL_NO_BARRIER | pfa::ABL_AGPR_OPND>(causal);
+            case 38: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV | pfa::ABL_NO_DMA | pfa::ABL_NO_BARRIER | pfa::VAR_PF8 | pfa::VAR_SETPRIO>(causal);
+            case 39: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_PF8 | pfa::VAR_SETPRIO>(causal);
             case 31: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_DMA>(causal);
             case 32: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_DMA | pfa::ABL_NO_BARRIER>(causal);
             case 14: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_QKIL>(causal);
