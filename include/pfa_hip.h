@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define PFA_ABI_VERSION 2
+#define PFA_ABI_VERSION 3
 
 typedef enum pfa_status {
     PFA_OK = 0,
@@ -139,6 +139,48 @@ int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream);
  */
 int pfa_fa3_weights(const pfa_fa3_args* a, void* w, int32_t w_dtype, int64_t w_stride_b, int64_t w_stride_h,
                     int64_t w_stride_q, void* stream);
+
+/*
+ * Backward pass (ABI v3).  The reference obtains gradients from autograd through its eager forward
+ * (flash_attention_3.py:152-262; its unit tests only require that gradients exist, tests/unit/
+ * test_flash_attention_3.py:137-160); this entry point computes dQ, dK, dV from q, k, v, o, dO and the forward's
+ * LSE by recomputation (three kernels: delta = rowsum(dO*O), dQ per query block, dK/dV per key block; no atomics,
+ * bitwise reproducible).  Masks: `causal` and `seqlens_k` (the general u8 masks are forward-only for now).
+ * All tensors [B,S,H,D] by element strides, last dim contiguous; gradients in `dtype_grad` (= dtype or fp32).
+ * `delta` is caller-provided scratch of pfa_fa3_bwd_workspace_bytes() bytes ([B,H,Sq] fp32).
+ */
+typedef struct pfa_fa3_bwd_args {
+    uint32_t size;              /* = sizeof(pfa_fa3_bwd_args) */
+    uint32_t flags;             /* must be 0 */
+    const void* q;
+    const void* k;
+    const void* v;
+    const void* o;              /* forward output */
+    const void* dout;           /* gradient of the forward output */
+    const float* lse;           /* [B,H,Sq] from the forward (pfa_fa3_args.lse) */
+    void* dq;
+    void* dk;
+    void* dv;
+    float* delta;               /* scratch [B,H,Sq] */
+    const int32_t* seqlens_k;   /* optional [B] */
+    int64_t q_stride_b, q_stride_h, q_stride_s;
+    int64_t k_stride_b, k_stride_h, k_stride_s;
+    int64_t v_stride_b, v_stride_h, v_stride_s;
+    int64_t o_stride_b, o_stride_h, o_stride_s;
+    int64_t do_stride_b, do_stride_h, do_stride_s;
+    int64_t dq_stride_b, dq_stride_h, dq_stride_s;
+    int64_t dk_stride_b, dk_stride_h, dk_stride_s;
+    int64_t dv_stride_b, dv_stride_h, dv_stride_s;
+    int32_t B, H, Sq, Sk, D;
+    int32_t dtype;              /* PFA_DTYPE_BF16 | PFA_DTYPE_FP16: q,k,v,o,dout */
+    int32_t dtype_grad;         /* = dtype or PFA_DTYPE_FP32: dq,dk,dv */
+    int32_t causal;
+    float   softmax_scale;
+    int32_t device_id;
+} pfa_fa3_bwd_args;
+
+size_t pfa_fa3_bwd_workspace_bytes(const pfa_fa3_bwd_args* a);
+int pfa_fa3_bwd(const pfa_fa3_bwd_args* a, void* stream);
 
 /*
  * Kernel-selection introspection for tests/bench: writes the name of the kernel variant pfa_fa3_fwd

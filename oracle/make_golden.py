@@ -10,6 +10,7 @@ What is stored is data only: shapes/seeds (the inputs are re-generated bit-exact
 
     photonic_flash_attention.core.flash_attention_3.FlashAttention3._flash_attention_forward
     photonic_flash_attention.core.flash_attention_3.FlashAttention3.forward            (G1 only)
+    torch.autograd through _flash_attention_forward (G8: dq, dk, dv for a fixed dout)
 
 run in fp32 on the CPU on the bf16-rounded inputs.  No reference
 source text is copied anywhere.
@@ -102,6 +103,23 @@ def sampled_case(name, B, H, S, D, seed, causal, heads, rows, note=""):
          head_sum=np.asarray(sums), head_abs_sum=np.asarray(asums))
 
 
+def grad_case(name, B, H, Sq, Sk, D, seed, causal, note=""):
+    """Gradients of the REAL reference's core by autograd (the only backward the reference has):
+    loss = sum(out * dout) with a fixed dout, so dq/dk/dv are the vector-Jacobian products the HIP backward returns."""
+    q, k, v = synth.qkv(B, H, Sq, Sk, D, seed, "bf16")
+    dout = torch.from_numpy(synth.normal_f32((B, Sq, H, D), seed + 5)).to(torch.bfloat16)
+    m = RefFA3(H * D, H).eval()
+    qf, kf, vf = (t.float().permute(0, 2, 1, 3).clone().requires_grad_(True) for t in (q, k, v))
+    mask = tril(Sq, Sk).expand(B, 1, Sq, Sk) if causal else None
+    o, _ = m._flash_attention_forward(qf, kf, vf, mask, False)
+    (o * dout.float().permute(0, 2, 1, 3)).sum().backward()
+    meta = dict(kind="grad", B=B, H=H, Sq=Sq, Sk=Sk, D=D, seed=seed, causal=causal, kv_valid=None, dtype="bf16",
+                layout="BSHD", in_checksum=input_checksum(q, k, v), dout_seed=seed + 5, note=note)
+    save(name, meta, out=o.detach().permute(0, 2, 1, 3).contiguous().numpy(),
+         dq=qf.grad.permute(0, 2, 1, 3).contiguous().numpy(), dk=kf.grad.permute(0, 2, 1, 3).contiguous().numpy(),
+         dv=vf.grad.permute(0, 2, 1, 3).contiguous().numpy())
+
+
 def module_case(name, B, S, E, H, seed):
     """G1b: whole-module plumbing (fused QKV chunk order, head split/merge, out_proj)."""
     m = RefFA3(E, H).eval()
@@ -143,6 +161,10 @@ def main():
     # dense-branch small / ragged shapes from the reference's fixture classes (conftest.py:31-38)
     full_case("g7_s97_d64", 2, 3, 97, 97, 64, 1010, note="ragged S, dense branch")
     full_case("g7_s512_d64_causal", 1, 4, 512, 512, 64, 1011, causal=True, note="S = tile edge, dense branch")
+    # G8: gradients (autograd through the reference core), dense and tiled branch
+    grad_case("g8_grad_s128_d128", 2, 2, 128, 128, 128, 3001, False, note="dense branch, autograd")
+    grad_case("g8_grad_s640_d64_causal", 1, 2, 640, 640, 64, 3002, True, note="tiled branch, causal, autograd")
+    grad_case("g8_grad_cross_200x333_d128", 1, 2, 200, 333, 128, 3003, False, note="Sq != Sk")
     # G6: BASELINE-shaped problems, sampled
     rows_1k = sorted(set(list(range(0, 8)) + list(range(500, 520)) + list(range(1016, 1024))))
     sampled_case("g6_c2", 4, 12, 1024, 64, 2002, False, [(0, 0), (1, 5), (3, 11)], rows_1k,

@@ -13,7 +13,7 @@ import os
 import threading
 from typing import Optional
 
-PFA_ABI_VERSION = 2
+PFA_ABI_VERSION = 3
 PFA_DTYPE_BF16, PFA_DTYPE_FP16, PFA_DTYPE_FP32 = 0, 1, 2
 PFA_FLAG_SPLIT_P = 0x1
 PFA_FLAG_NO_XCD_MAP = 0x2
@@ -24,6 +24,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "libpfa_hip.so")
 EXPORTS = (
     "pfa_abi_version", "pfa_status_string", "pfa_device_supported", "pfa_last_hip_error",
     "pfa_fa3_workspace_bytes", "pfa_fa3_check", "pfa_fa3_fwd", "pfa_fa3_describe", "pfa_fa3_weights",
+    "pfa_fa3_bwd", "pfa_fa3_bwd_workspace_bytes",
 )
 
 
@@ -46,6 +47,17 @@ class PfaFa3Args(C.Structure):
         ("mask_stride_b", C.c_int64), ("mask_stride_h", C.c_int64), ("mask_stride_q", C.c_int64),
         ("mask_stride_k", C.c_int64),
     ]
+
+
+class PfaFa3BwdArgs(C.Structure):
+    """Mirror of ``struct pfa_fa3_bwd_args`` (include/pfa_hip.h)."""
+    _fields_ = (
+        [("size", C.c_uint32), ("flags", C.c_uint32)]
+        + [(n, C.c_void_p) for n in ("q", "k", "v", "o", "dout", "lse", "dq", "dk", "dv", "delta", "seqlens_k")]
+        + [(f"{t}_stride_{a}", C.c_int64) for t in ("q", "k", "v", "o", "do", "dq", "dk", "dv") for a in "bhs"]
+        + [(n, C.c_int32) for n in ("B", "H", "Sq", "Sk", "D", "dtype", "dtype_grad", "causal")]
+        + [("softmax_scale", C.c_float), ("device_id", C.c_int32)]
+    )
 
 
 class PfaError(RuntimeError):
@@ -89,6 +101,10 @@ def load(path: Optional[str] = None):
         lib.pfa_fa3_weights.restype = C.c_int
         lib.pfa_fa3_weights.argtypes = [C.POINTER(PfaFa3Args), C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int64,
                                         C.c_void_p]
+        lib.pfa_fa3_bwd.restype = C.c_int
+        lib.pfa_fa3_bwd.argtypes = [C.POINTER(PfaFa3BwdArgs), C.c_void_p]
+        lib.pfa_fa3_bwd_workspace_bytes.restype = C.c_size_t
+        lib.pfa_fa3_bwd_workspace_bytes.argtypes = [C.POINTER(PfaFa3BwdArgs)]
         lib.pfa_fa3_describe.restype = C.c_int
         lib.pfa_fa3_describe.argtypes = [C.POINTER(PfaFa3Args), C.c_char_p, C.c_size_t]
         v = lib.pfa_abi_version()

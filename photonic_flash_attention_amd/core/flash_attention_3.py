@@ -131,8 +131,17 @@ class FlashAttention3(nn.Module):
             raise RuntimeError(
                 "FlashAttention3 runs on MI355X only: move the module and its inputs to a GPU "
                 "(this package ships no CPU or eager implementation of the core)")
-        if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
-            raise RuntimeError("forward-only kernel: call under torch.no_grad() (backward is not implemented)")
+        needs_grad = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)
+        if needs_grad:
+            # differentiable path: HIP forward (with LSE) + HIP backward (pfa_fa3_bwd).  It covers what the backward
+            # kernels cover: bf16/fp16 operands, causal flag, no explicit mask, no weights.
+            if attention_mask is not None or need_weights or q.dtype == torch.float32:
+                raise NotImplementedError(
+                    "autograd through the HIP path supports bf16/fp16 modules with is_causal only "
+                    "(no attention_mask, no need_weights); use torch.no_grad() for the other forward modes")
+            if self.training and self.dropout > 0:
+                raise NotImplementedError("attention dropout in training mode is not implemented on the HIP path")
+            return ops.fa3_attention(q, k, v, causal=is_causal, softmax_scale=self.scaling), None
         if self.training and self.dropout > 0:
             raise NotImplementedError("attention dropout in training mode is not implemented on the HIP path")
 

@@ -1,0 +1,499 @@
+// fa3_bwd_kernels.h -- Flash-Attention BACKWARD for MI355X (gfx950): dQ, dK, dV from the forward's LSE.
+//
+// The reference gets its backward from autograd through the eager forward (flash_attention_3.py:152-262;
+// tests/unit/test_flash_attention_3.py:137-160 only require that gradients exist).  Here it is three kernels
+// that recompute P = exp(scale*S - LSE) tile by tile instead of storing the S x S matrices:
+//
+//   fa3_bwd_delta   delta[b,h,i] = sum_d dO[i,d] * O[i,d]                       (memory bound)
+//   fa3_bwd_dq      per 256-row Q block (8 waves x 32 rows, same geometry / LDS images / DMA as the forward):
+//                     S^T = K Q^T, dP^T = V dO^T, dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T
+//   fa3_bwd_dkdv    per 128-key block (4 waves x 32 keys, one wave per SIMD: K^T/V^T operand fragments and the
+//                   dK^T/dV^T accumulators of the block stay in registers), streaming Q and dO tiles:
+//                     S = Q K^T, dP = dO V^T, dV^T += dO^T P, dS = P o (dP - delta), dK^T += Q^T dS
+//
+// dQ is recomputed from its own pass (7 MFMA products in total instead of 5) rather than summed across key
+// blocks with float atomics: bitwise reproducible, no dQ zero-fill, no atomic floor (cdna guide Appendix B).
+// Operand maps are those of fa3_fwd_kernel.h: the accumulator of the first product, converted to bf16/f16, is
+// the B operand of the product that contracts over its ROW index (k order permuted), and the other operand of
+// that product is fetched in the same order by ds_read_b64_tr_b16 from the row-major, XOR-swizzled tile image.
+#pragma once
+#include "fa3_fwd_kernel.h"
+
+namespace pfa {
+
+struct BwdParams {
+    const void* q;
+    const void* k;
+    const void* v;
+    const void* o;
+    const void* dout;
+    const float* lse;      // [B,H,Sq] natural log
+    float* delta;          // [B,H,Sq] workspace
+    void* dq;
+    void* dk;
+    void* dv;
+    const int32_t* seqlens_k;
+    int64_t q_sb, q_sh, q_ss, k_sb, k_sh, k_ss, v_sb, v_sh, v_ss;
+    int64_t o_sb, o_sh, o_ss, do_sb, do_sh, do_ss;
+    int64_t dq_sb, dq_sh, dq_ss, dk_sb, dk_sh, dk_ss, dv_sb, dv_sh, dv_ss;
+    int32_t B, H, Sq, Sk;
+    int32_t nblk;          // Q blocks (dq) or key blocks (dkdv)
+    float scale;           // softmax scale
+    float scale_log2;      // scale * log2(e)
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// delta = rowsum(dO o O): one wave per 64 rows? -> one thread per (row, 8-element chunk), reduced in-wave.
+template <typename T, int D>
+__global__ __launch_bounds__(256) void fa3_bwd_delta_kernel(const BwdParams p) {
+    using v8 = typename Elem<T>::v8;
+    constexpr int CPR = D / 8;                       // 16-byte chunks per row
+    constexpr int ROWS_PER_BLOCK = 256 / CPR;
+    const int bh = blockIdx.y;
+    const int b = bh / p.H, hh = bh - b * p.H;
+    const int row = blockIdx.x * ROWS_PER_BLOCK + threadIdx.x / CPR;
+    const int ch = threadIdx.x % CPR;
+    float acc = 0.f;
+    if (row < p.Sq) {
+        const T* op = (const T*)p.o + (int64_t)b * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)row * p.o_ss + ch * 8;
+        const T* gp = (const T*)p.dout + (int64_t)b * p.do_sb + (int64_t)hh * p.do_sh + (int64_t)row * p.do_ss + ch * 8;
+        const v8 a = *(const v8*)op, g = *(const v8*)gp;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += (float)a[e] * (float)g[e];
+    }
+#pragma unroll
+    for (int off = CPR / 2; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+    if (row < p.Sq && ch == 0) p.delta[((int64_t)b * p.H + hh) * p.Sq + row] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Shared tile machinery: 64-row x D tile images (two per stage), LDS-DMA by buffer descriptor, swizzled.
+template <int D, int NW>
+struct TileDma {
+    static constexpr int TILE_BYTES = BLOCK_N * D * 2;
+    static constexpr int PIECES = TILE_BYTES / 1024;
+    static constexpr int PPW = PIECES / NW;
+    uint32_t off_a[PPW], off_b[PPW];     // per-lane byte offsets inside the two source slabs
+    __device__ __forceinline__ void init(int wave, int lane, int64_t stride_a, int64_t stride_b) {
+        const int R0 = 4 * wave + (lane >> 4);
+        const int sw = ((R0 & 3) << 2) | ((R0 >> 2) & 3);
+        const int cc = (lane & 15) ^ sw;
+#pragma unroll
+        for (int t = 0; t < PPW; ++t) {
+            int row, col;
+            if constexpr (D == 128) {
+                row = R0 + 4 * NW * t;
+                col = cc * 8;
+            } else {
+                row = 2 * (R0 + 4 * NW * t) + (cc >> 3);
+                col = (cc & 7) * 8;
+            }
+            off_a[t] = (uint32_t)(row * (int)stride_a + col) * 2u;
+            off_b[t] = (uint32_t)(row * (int)stride_b + col) * 2u;
+        }
+    }
+    // tile j of slab A -> LDS at lds_a, of slab B -> lds_b (rows past `rows` read as zeros)
+    __device__ __forceinline__ void issue(int wave, int j, const char* base_a, int64_t stride_a, int64_t slab_a,
+                                          uint32_t lds_a, const char* base_b, int64_t stride_b, int64_t slab_b,
+                                          uint32_t lds_b) const {
+        const int64_t sa = (int64_t)j * BLOCK_N * stride_a * 2, sb = (int64_t)j * BLOCK_N * stride_b * 2;
+        const srd_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(base_a + sa), 0, (int)max((int64_t)0, slab_a - sa), 0x00020000);
+        const srd_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(base_b + sb), 0, (int)max((int64_t)0, slab_b - sb), 0x00020000);
+#pragma unroll
+        for (int t = 0; t < PPW; ++t) {
+            lds_dma16_buf(ra, off_a[t], lds_a + (wave + NW * t) * 1024);
+            lds_dma16_buf(rb, off_b[t], lds_b + (wave + NW * t) * 1024);
+        }
+    }
+};
+
+// per-lane read offsets inside one tile image
+template <typename T, int D>
+struct TileRead {
+    static constexpr int KS = D / 16, DB = D / 32, NS2 = (D == 128) ? 1 : 2;
+    uint32_t row_off[KS];            // row read (32 rows r, chunk 2ks+h), +HALF_TILE for rows 32..63
+    uint32_t tr_off[NS2][DB][2];     // transposed read (see fa3_fwd_kernel.h)
+    __device__ __forceinline__ void init(int lane, uint32_t base) {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) row_off[ks] = base + tile_off<D>(r, 2 * ks + h);
+        const int g1 = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
+#pragma unroll
+        for (int s2 = 0; s2 < NS2; ++s2)
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int hi = 0; hi < 2; ++hi)
+                    tr_off[s2][db][hi] = base + tile_off<D>(16 * s2 + 4 * h + tq + 8 * hi, db * 4 + 2 * g1 + (tp >> 1)) + 8 * (tp & 1);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// dQ: forward geometry.  LDS stage = [K image | V image], double buffered (64 KiB at D = 128).
+template <typename T, int D, bool CAUSAL, typename OT>
+__global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
+    using E = Elem<T>;
+    using v8 = typename E::v8;
+    using v4 = typename E::v4;
+    typedef __attribute__((address_space(3))) v8 lds_v8;
+    constexpr int NW = 8, BLOCK_M = 256, KS = D / 16, DB = D / 32;
+    constexpr int TILE_BYTES = BLOCK_N * D * 2, BUF_BYTES = 2 * TILE_BYTES, HALF_TILE = TILE_BYTES / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(lds_char*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int BH = p.B * p.H, n = blockIdx.x, qrank = n / BH, bh = n - qrank * BH;
+    const int qblk = CAUSAL ? (p.nblk - 1 - qrank) : qrank;
+    const int b = bh / p.H, hh = bh - b * p.H;
+    const int q0 = qblk * BLOCK_M, wave_q0 = q0 + wave * WAVE_M, my_q = wave_q0 + r;
+
+    int kv_len = p.Sk;
+    if (p.seqlens_k) kv_len = min(kv_len, max(p.seqlens_k[b], 0));
+    const int kv_end = CAUSAL ? min(kv_len, q0 + BLOCK_M) : kv_len;
+    const int wave_kv_end = CAUSAL ? min(kv_len, wave_q0 + WAVE_M) : kv_len;
+    const int nt = (kv_end + BLOCK_N - 1) / BLOCK_N;
+
+    const T* qp = (const T*)p.q + (int64_t)b * p.q_sb + (int64_t)hh * p.q_sh;
+    const T* gp = (const T*)p.dout + (int64_t)b * p.do_sb + (int64_t)hh * p.do_sh;
+    const char* kp = (const char*)((const T*)p.k + (int64_t)b * p.k_sb + (int64_t)hh * p.k_sh);
+    const char* vp = (const char*)((const T*)p.v + (int64_t)b * p.v_sb + (int64_t)hh * p.v_sh);
+    const int64_t k_slab = ((int64_t)(p.Sk - 1) * p.k_ss + D) * 2, v_slab = ((int64_t)(p.Sk - 1) * p.v_ss + D) * 2;
+
+    const int qrow = min(my_q, p.Sq - 1);
+    v8 qf[KS], gf[KS];                       // Q and dO fragments of this lane's row (B operands)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        qf[ks] = *(const v8*)(qp + (int64_t)qrow * p.q_ss + 16 * ks + 8 * h);
+        gf[ks] = *(const v8*)(gp + (int64_t)qrow * p.do_ss + 16 * ks + 8 * h);
+    }
+    const int64_t stat = ((int64_t)b * p.H + hh) * p.Sq + qrow;
+    const float lse = p.lse[stat];
+    const float delta = p.delta[stat];
+    const bool dead = !(lse > -INFINITY) || my_q >= p.Sq;
+    const float lse2 = dead ? 0.f : lse * 1.4426950408889634f;
+    const float c = p.scale_log2;
+
+    TileDma<D, NW> dma;
+    dma.init(wave, lane, p.k_ss, p.v_ss);
+    TileRead<T, D> rk;                       // K image: row reads (S^T) and transposed reads (dQ^T)
+    rk.init(lane, smem_base);
+
+    f32x16 acc[DB];                          // dQ^T[d][q]
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    auto compute = [&](auto bufc, int key_base) {
+        constexpr int BOFF = decltype(bufc)::value * BUF_BYTES;
+        f32x16 s[2], dp[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                s[kb][e] = 0.f;
+                dp[kb][e] = 0.f;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const v8 ka = *(const lds_v8*)(uintptr_t)(rk.row_off[ks] + BOFF + kb * HALF_TILE);
+                const v8 va = *(const lds_v8*)(uintptr_t)(rk.row_off[ks] + BOFF + TILE_BYTES + kb * HALF_TILE);
+                s[kb] = E::mfma(ka, qf[ks], s[kb]);          // S^T[key][q]
+                dp[kb] = E::mfma(va, gf[ks], dp[kb]);        // dP^T[key][q]
+            }
+        }
+        const bool need_mask = (key_base + BLOCK_N > kv_len) || (CAUSAL && key_base + BLOCK_N - 1 > wave_q0);
+        // dS^T = P^T o (dP^T - delta), P^T = exp2(c S^T - lse2)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float pe = fast_exp2(__builtin_fmaf(s[kb][e], c, -lse2));
+                if (need_mask) {
+                    const int key = key_base + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    bool ok = key < kv_len;
+                    if (CAUSAL) ok = ok && (key <= my_q);
+                    pe = ok ? pe : 0.f;
+                }
+                s[kb][e] = dead ? 0.f : pe * (dp[kb][e] - delta);
+            }
+        // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                v8 ds;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ds[e] = (T)s[kb][8 * s2 + e];
+                constexpr int S2I = (D == 128) ? 0 : 1;
+                const int koffs = BOFF + kb * HALF_TILE + ((D == 128) ? s2 * 16 * 256 : 0);
+#pragma unroll
+                for (int db = 0; db < DB; ++db) {
+                    const v4 lo = E::tr_read((const lds_char*)(uintptr_t)(rk.tr_off[s2 * S2I][db][0] + koffs));
+                    const v4 hi4 = E::tr_read((const lds_char*)(uintptr_t)(rk.tr_off[s2 * S2I][db][1] + koffs));
+                    v8 a;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a[e] = lo[e];
+                        a[4 + e] = hi4[e];
+                    }
+                    acc[db] = E::mfma(a, ds, acc[db]);
+                }
+            }
+    };
+    auto step = [&](auto bufc, int j) {
+        constexpr int BUF = decltype(bufc)::value;
+        if (j + 1 < nt)
+            dma.issue(wave, j + 1, kp, p.k_ss, k_slab, smem_base + (BUF ^ 1) * BUF_BYTES, vp, p.v_ss, v_slab,
+                      smem_base + (BUF ^ 1) * BUF_BYTES + TILE_BYTES);
+        if (j * BLOCK_N < wave_kv_end) compute(bufc, j * BLOCK_N);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+    };
+    if (nt > 0) dma.issue(wave, 0, kp, p.k_ss, k_slab, smem_base, vp, p.v_ss, v_slab, smem_base + TILE_BYTES);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        asm volatile("" : "+v"(qf[ks]));
+        asm volatile("" : "+v"(gf[ks]));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int j = 0; j < nt; j += 2) {
+        step(IC<0>{}, j);
+        if (j + 1 < nt) step(IC<1>{}, j + 1);
+    }
+    if (my_q < p.Sq) {
+        OT* orow = (OT*)p.dq + (int64_t)b * p.dq_sb + (int64_t)hh * p.dq_sh + (int64_t)my_q * p.dq_ss;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = db * 32 + 8 * g + 4 * h;
+                if constexpr (sizeof(OT) == 4) {
+                    f32x4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = acc[db][4 * g + e] * p.scale;
+                    *(f32x4*)(orow + d) = w;
+                } else {
+                    v4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = (T)(acc[db][4 * g + e] * p.scale);
+                    *(v4*)(orow + d) = w;
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// dK, dV: key-stationary.  Workgroup = 4 waves x 32 keys = 128 keys; LDS stage = [Q image | dO image] (64 rows).
+template <typename T, int D, bool CAUSAL, typename OT>
+__global__ __launch_bounds__(256, 1) void fa3_bwd_dkdv_kernel(const BwdParams p) {
+    using E = Elem<T>;
+    using v8 = typename E::v8;
+    using v4 = typename E::v4;
+    typedef __attribute__((address_space(3))) v8 lds_v8;
+    constexpr int NW = 4, BLOCK_K = 128, KS = D / 16, DB = D / 32;
+    constexpr int TILE_BYTES = BLOCK_N * D * 2, BUF_BYTES = 2 * TILE_BYTES, HALF_TILE = TILE_BYTES / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t smem_base = (uint32_t)(uintptr_t)(lds_char*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int BH = p.B * p.H, n = blockIdx.x, krank = n / BH, bh = n - krank * BH;
+    const int kblk = krank;                      // causal: low key blocks see the most query rows -> first
+    const int b = bh / p.H, hh = bh - b * p.H;
+    const int k0 = kblk * BLOCK_K, wave_k0 = k0 + wave * 32, my_key = wave_k0 + r;
+
+    int kv_len = p.Sk;
+    if (p.seqlens_k) kv_len = min(kv_len, max(p.seqlens_k[b], 0));
+    const bool key_ok = my_key < kv_len;
+    // query tiles this block needs: causal -> rows >= k0
+    const int t_first = CAUSAL ? (k0 / BLOCK_N) : 0;
+    const int nt = (p.Sq + BLOCK_N - 1) / BLOCK_N;
+
+    const char* qp = (const char*)((const T*)p.q + (int64_t)b * p.q_sb + (int64_t)hh * p.q_sh);
+    const char* gp = (const char*)((const T*)p.dout + (int64_t)b * p.do_sb + (int64_t)hh * p.do_sh);
+    const T* kp = (const T*)p.k + (int64_t)b * p.k_sb + (int64_t)hh * p.k_sh;
+    const T* vp = (const T*)p.v + (int64_t)b * p.v_sb + (int64_t)hh * p.v_sh;
+    const int64_t q_slab = ((int64_t)(p.Sq - 1) * p.q_ss + D) * 2, g_slab = ((int64_t)(p.Sq - 1) * p.do_ss + D) * 2;
+    const float* lse_p = p.lse + ((int64_t)b * p.H + hh) * p.Sq;
+    const float* del_p = p.delta + ((int64_t)b * p.H + hh) * p.Sq;
+    // per-row constants of a 64-row tile, staged through LDS beside the tile: st[buf][0][64] = -lse/scale (or -inf
+    // for rows that do not exist / are fully masked), st[buf][1][64] = -delta.  Thread t < 64 moves row t.
+    constexpr int STAT_BASE = 2 * BUF_BYTES;
+    typedef __attribute__((address_space(3))) float lds_float;
+    typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+    float st_l = 0.f, st_d = 0.f;
+    auto stat_load = [&](int j) {
+        if (tid < BLOCK_N) {
+            const int qi = j * BLOCK_N + tid;
+            const bool live = qi < p.Sq;
+            const float l = live ? lse_p[qi] : -INFINITY;
+            st_l = (l > -INFINITY) ? -l / p.scale : -INFINITY;
+            st_d = live ? -del_p[qi] : 0.f;
+        }
+    };
+    auto stat_store = [&](int buf) {
+        if (tid < BLOCK_N) {
+            *(lds_float*)(uintptr_t)(smem_base + STAT_BASE + buf * 512 + tid * 4) = st_l;
+            *(lds_float*)(uintptr_t)(smem_base + STAT_BASE + buf * 512 + 256 + tid * 4) = st_d;
+        }
+    };
+
+    const int krow = min(my_key, p.Sk - 1);
+    v8 kf[KS], vf[KS];                       // K^T / V^T B-operand fragments: lane (key r, h) holds X[key][16ks+8h..+7]
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = *(const v8*)(kp + (int64_t)krow * p.k_ss + 16 * ks + 8 * h);
+        vf[ks] = *(const v8*)(vp + (int64_t)krow * p.v_ss + 16 * ks + 8 * h);
+    }
+    const float c = p.scale_log2;
+
+    TileDma<D, NW> dma;
+    dma.init(wave, lane, p.q_ss, p.do_ss);
+    TileRead<T, D> rq;
+    rq.init(lane, smem_base);
+
+    f32x16 dk[DB], dv[DB];                   // dK^T[d][key], dV^T[d][key]
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            dk[i][e] = 0.f;
+            dv[i][e] = 0.f;
+        }
+
+    // one 32-row half of a 64-row Q/dO tile
+    auto half = [&](auto bufc, auto hc, int q_base) {
+        constexpr int BOFF = decltype(bufc)::value * BUF_BYTES;
+        constexpr int HOFF = decltype(hc)::value * HALF_TILE;
+        // accumulators start at the per-row constants: S - lse/scale , dP - delta  (rows = queries = registers)
+        f32x16 s, dpv;
+        {
+            constexpr int SOFF = STAT_BASE + decltype(bufc)::value * 512 + decltype(hc)::value * 128;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {   // rows 8g + 4h .. +3 of this half: one 16-byte broadcast read each
+                const f32x4 lv = *(const lds_f32x4*)(uintptr_t)(smem_base + SOFF + (8 * g + 4 * h) * 4);
+                const f32x4 dv4 = *(const lds_f32x4*)(uintptr_t)(smem_base + SOFF + 256 + (8 * g + 4 * h) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s[4 * g + e] = lv[e];
+                    dpv[4 * g + e] = dv4[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const v8 qa = *(const lds_v8*)(uintptr_t)(rq.row_off[ks] + BOFF + HOFF);
+            const v8 ga = *(const lds_v8*)(uintptr_t)(rq.row_off[ks] + BOFF + TILE_BYTES + HOFF);
+            s = E::mfma(qa, kf[ks], s);          // S[q][key] - lse/scale
+            dpv = E::mfma(ga, vf[ks], dpv);      // dP[q][key] - delta
+        }
+        v8 pb[2], dsb[2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int qi = q_base + (e & 3) + 8 * (e >> 2) + 4 * h;
+            bool ok = key_ok;
+            if (CAUSAL) ok = ok && (my_key <= qi);
+            const float pe = ok ? fast_exp2(s[e] * c) : 0.f;      // exp(scale*S - lse); rows staged as -inf give 0
+            const float de = pe * dpv[e];
+            pb[e >> 3][e & 7] = (T)pe;
+            dsb[e >> 3][e & 7] = (T)de;
+        }
+        // dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            constexpr int S2I = (D == 128) ? 0 : 1;
+            const int koffs = BOFF + HOFF + ((D == 128) ? s2 * 16 * 256 : 0);
+#pragma unroll
+            for (int db = 0; db < DB; ++db) {
+                v8 a;
+                {
+                    const v4 lo = E::tr_read((const lds_char*)(uintptr_t)(rq.tr_off[s2 * S2I][db][0] + koffs + TILE_BYTES));
+                    const v4 hi4 = E::tr_read((const lds_char*)(uintptr_t)(rq.tr_off[s2 * S2I][db][1] + koffs + TILE_BYTES));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a[e] = lo[e];
+                        a[4 + e] = hi4[e];
+                    }
+                }
+                dv[db] = E::mfma(a, pb[s2], dv[db]);
+                {
+                    const v4 lo = E::tr_read((const lds_char*)(uintptr_t)(rq.tr_off[s2 * S2I][db][0] + koffs));
+                    const v4 hi4 = E::tr_read((const lds_char*)(uintptr_t)(rq.tr_off[s2 * S2I][db][1] + koffs));
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        a[e] = lo[e];
+                        a[4 + e] = hi4[e];
+                    }
+                }
+                dk[db] = E::mfma(a, dsb[s2], dk[db]);
+            }
+        }
+    };
+    auto step = [&](auto bufc, int j) {
+        constexpr int BUF = decltype(bufc)::value;
+        if (j + 1 < nt) {
+            dma.issue(wave, j + 1, qp, p.q_ss, q_slab, smem_base + (BUF ^ 1) * BUF_BYTES, gp, p.do_ss, g_slab,
+                      smem_base + (BUF ^ 1) * BUF_BYTES + TILE_BYTES);
+            stat_load(j + 1);                    // lands under this tile's math, written to LDS before the barrier
+        }
+        const int q_base = j * BLOCK_N;
+        // causal: a 32-row half whose last row is above this wave's first key contributes nothing
+        if (!CAUSAL || q_base + 31 >= wave_k0) half(bufc, IC<0>{}, q_base);
+        if (q_base + 32 < p.Sq && (!CAUSAL || q_base + 63 >= wave_k0)) half(bufc, IC<1>{}, q_base + 32);
+        if (j + 1 < nt) stat_store(BUF ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+    };
+    if (t_first < nt) {
+        dma.issue(wave, t_first, qp, p.q_ss, q_slab, smem_base, gp, p.do_ss, g_slab, smem_base + TILE_BYTES);
+        stat_load(t_first);
+        stat_store(0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        asm volatile("" : "+v"(kf[ks]));
+        asm volatile("" : "+v"(vf[ks]));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int j = t_first; j < nt; j += 2) {
+        step(IC<0>{}, j);
+        if (j + 1 < nt) step(IC<1>{}, j + 1);
+    }
+    if (my_key < p.Sk) {
+        OT* krow_o = (OT*)p.dk + (int64_t)b * p.dk_sb + (int64_t)hh * p.dk_sh + (int64_t)my_key * p.dk_ss;
+        OT* vrow_o = (OT*)p.dv + (int64_t)b * p.dv_sb + (int64_t)hh * p.dv_sh + (int64_t)my_key * p.dv_ss;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = db * 32 + 8 * g + 4 * h;
+                if constexpr (sizeof(OT) == 4) {
+                    f32x4 wk, wv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        wk[e] = dk[db][4 * g + e] * p.scale;
+                        wv[e] = dv[db][4 * g + e];
+                    }
+                    *(f32x4*)(krow_o + d) = wk;
+                    *(f32x4*)(vrow_o + d) = wv;
+                } else {
+                    v4 wk, wv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        wk[e] = (T)(dk[db][4 * g + e] * p.scale);
+                        wv[e] = (T)dv[db][4 * g + e];
+                    }
+                    *(v4*)(krow_o + d) = wk;
+                    *(v4*)(vrow_o + d) = wv;
+                }
+            }
+    }
+}
+
+}  // namespace pfa

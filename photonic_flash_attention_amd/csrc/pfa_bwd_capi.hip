@@ -1,0 +1,124 @@
+// pfa_bwd_capi.hip -- C ABI of the backward pass (include/pfa_hip.h: pfa_fa3_bwd).  Separate translation unit:
+// the key-stationary dK/dV kernel runs one wave per SIMD on the whole register file and is compiled with
+// -mllvm -amdgpu-mfma-vgpr-form (see Makefile) so that hipcc keeps its MFMA accumulators in place.
+#include "pfa_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <string.h>
+
+#include "fa3_bwd_kernels.h"
+
+namespace {
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int check_bwd(const pfa_fa3_bwd_args* a) {
+    if (!a) return PFA_ERR_NULL;
+    if (a->size != sizeof(pfa_fa3_bwd_args)) return PFA_ERR_STRUCT_SIZE;
+    if (a->flags) return PFA_ERR_FLAGS;
+    if (!a->q || !a->k || !a->v || !a->o || !a->dout || !a->lse || !a->dq || !a->dk || !a->dv || !a->delta) return PFA_ERR_NULL;
+    if (a->B <= 0 || a->H <= 0 || a->Sq <= 0 || a->Sk <= 0) return PFA_ERR_SHAPE;
+    if (a->D != 64 && a->D != 128) return PFA_ERR_HEAD_DIM;
+    if (a->dtype != PFA_DTYPE_BF16 && a->dtype != PFA_DTYPE_FP16) return PFA_ERR_DTYPE;
+    if (a->dtype_grad != a->dtype && a->dtype_grad != PFA_DTYPE_FP32) return PFA_ERR_DTYPE;
+    if (!(a->softmax_scale > 0.f) || !isfinite(a->softmax_scale)) return PFA_ERR_SHAPE;
+    const int64_t in_st[] = {a->q_stride_b, a->q_stride_h, a->q_stride_s, a->k_stride_b, a->k_stride_h, a->k_stride_s,
+                             a->v_stride_b, a->v_stride_h, a->v_stride_s, a->o_stride_b, a->o_stride_h, a->o_stride_s,
+                             a->do_stride_b, a->do_stride_h, a->do_stride_s};
+    for (int64_t s : in_st)
+        if (s % 8) return PFA_ERR_STRIDE;
+    const int64_t out_st[] = {a->dq_stride_b, a->dq_stride_h, a->dq_stride_s, a->dk_stride_b, a->dk_stride_h,
+                              a->dk_stride_s, a->dv_stride_b, a->dv_stride_h, a->dv_stride_s};
+    for (int64_t s : out_st)
+        if (s % 4) return PFA_ERR_STRIDE;
+    const void* ptrs[] = {a->q, a->k, a->v, a->o, a->dout, a->dq, a->dk, a->dv};
+    for (const void* p : ptrs)
+        if (!al16(p)) return PFA_ERR_ALIGN;
+    const int64_t slabs[] = {((int64_t)(a->Sk - 1) * a->k_stride_s + a->D) * 2, ((int64_t)(a->Sk - 1) * a->v_stride_s + a->D) * 2,
+                             ((int64_t)(a->Sq - 1) * a->q_stride_s + a->D) * 2, ((int64_t)(a->Sq - 1) * a->do_stride_s + a->D) * 2};
+    for (int64_t s : slabs)
+        if (s > 0x7fffffffLL || s <= 0) return PFA_ERR_SHAPE;
+    return PFA_OK;
+}
+
+template <typename T, int D>
+void pick_kernels(bool causal, bool g32, const void*& delta, const void*& dq, const void*& dkdv) {
+    delta = (const void*)&pfa::fa3_bwd_delta_kernel<T, D>;
+    if (causal) {
+        dq = g32 ? (const void*)&pfa::fa3_bwd_dq_kernel<T, D, true, float> : (const void*)&pfa::fa3_bwd_dq_kernel<T, D, true, T>;
+        dkdv = g32 ? (const void*)&pfa::fa3_bwd_dkdv_kernel<T, D, true, float> : (const void*)&pfa::fa3_bwd_dkdv_kernel<T, D, true, T>;
+    } else {
+        dq = g32 ? (const void*)&pfa::fa3_bwd_dq_kernel<T, D, false, float> : (const void*)&pfa::fa3_bwd_dq_kernel<T, D, false, T>;
+        dkdv = g32 ? (const void*)&pfa::fa3_bwd_dkdv_kernel<T, D, false, float> : (const void*)&pfa::fa3_bwd_dkdv_kernel<T, D, false, T>;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t pfa_fa3_bwd_workspace_bytes(const pfa_fa3_bwd_args* a) {
+    if (!a || a->B <= 0 || a->H <= 0 || a->Sq <= 0) return 0;
+    return (size_t)a->B * a->H * a->Sq * sizeof(float);
+}
+
+int pfa_fa3_bwd(const pfa_fa3_bwd_args* a, void* stream) {
+    const int st = check_bwd(a);
+    if (st != PFA_OK) return st;
+    pfa::BwdParams p;
+    p.q = a->q; p.k = a->k; p.v = a->v; p.o = a->o; p.dout = a->dout; p.lse = a->lse; p.delta = a->delta;
+    p.dq = a->dq; p.dk = a->dk; p.dv = a->dv; p.seqlens_k = a->seqlens_k;
+    p.q_sb = a->q_stride_b; p.q_sh = a->q_stride_h; p.q_ss = a->q_stride_s;
+    p.k_sb = a->k_stride_b; p.k_sh = a->k_stride_h; p.k_ss = a->k_stride_s;
+    p.v_sb = a->v_stride_b; p.v_sh = a->v_stride_h; p.v_ss = a->v_stride_s;
+    p.o_sb = a->o_stride_b; p.o_sh = a->o_stride_h; p.o_ss = a->o_stride_s;
+    p.do_sb = a->do_stride_b; p.do_sh = a->do_stride_h; p.do_ss = a->do_stride_s;
+    p.dq_sb = a->dq_stride_b; p.dq_sh = a->dq_stride_h; p.dq_ss = a->dq_stride_s;
+    p.dk_sb = a->dk_stride_b; p.dk_sh = a->dk_stride_h; p.dk_ss = a->dk_stride_s;
+    p.dv_sb = a->dv_stride_b; p.dv_sh = a->dv_stride_h; p.dv_ss = a->dv_stride_s;
+    p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
+    p.scale = a->softmax_scale;
+    p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
+
+    const void *kdelta, *kdq, *kdkdv;
+    const bool causal = a->causal != 0, g32 = a->dtype_grad == PFA_DTYPE_FP32;
+    if (a->dtype == PFA_DTYPE_BF16) {
+        if (a->D == 128) pick_kernels<__bf16, 128>(causal, g32, kdelta, kdq, kdkdv);
+        else pick_kernels<__bf16, 64>(causal, g32, kdelta, kdq, kdkdv);
+    } else {
+        if (a->D == 128) pick_kernels<_Float16, 128>(causal, g32, kdelta, kdq, kdkdv);
+        else pick_kernels<_Float16, 64>(causal, g32, kdelta, kdq, kdkdv);
+    }
+    int prev = -1;
+    hipError_t e = hipGetDevice(&prev);
+    if (e == hipSuccess && prev != a->device_id) e = hipSetDevice(a->device_id);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return PFA_ERR_DEVICE;
+    }
+    const int lds = 2 * 2 * pfa::BLOCK_N * a->D * 2;
+    const int BH = a->B * a->H;
+    void* args[] = {&p};
+    const int rows_per_block = 256 / (a->D / 8);
+    p.nblk = 0;
+    e = hipLaunchKernel(kdelta, dim3((a->Sq + rows_per_block - 1) / rows_per_block, BH), dim3(256), args, 0, (hipStream_t)stream);
+    if (e == hipSuccess) {
+        p.nblk = (a->Sq + 255) / 256;
+        e = hipLaunchKernel(kdq, dim3((unsigned)(p.nblk * BH)), dim3(512), args, (size_t)lds, (hipStream_t)stream);
+    }
+    if (e == hipSuccess) {
+        p.nblk = (a->Sk + 127) / 128;
+        if (lds + 1024 > 64 * 1024)   // tile stages + the per-row constants exceed the default 64 KiB dynamic-LDS limit
+            (void)hipFuncSetAttribute(kdkdv, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 1024);
+        e = hipLaunchKernel(kdkdv, dim3((unsigned)(p.nblk * BH)), dim3(256), args, (size_t)lds + 1024, (hipStream_t)stream);
+    }
+    if (prev != a->device_id) (void)hipSetDevice(prev);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return PFA_ERR_LAUNCH;
+    }
+    return PFA_OK;
+}
+
+}  // extern "C"

@@ -180,3 +180,69 @@ def fa3_forward_bshd(q, k, v, **kw):
     """Same, for operands laid out ``[B,S,H,D]``; returns ``[B,Sq,H,D]`` (+ lse)."""
     res = fa3_forward(q.permute(0, 2, 1, 3), k.permute(0, 2, 1, 3), v.permute(0, 2, 1, 3), **kw)
     return (res[0].permute(0, 2, 1, 3),) + tuple(res[1:])
+
+
+def fa3_backward(q, k, v, out, dout, lse, *, causal: bool = False, seqlens_k=None,
+                 softmax_scale: Optional[float] = None, grad_dtype: Optional[torch.dtype] = None):
+    """dQ, dK, dV of ``fa3_forward`` (``pfa_fa3_bwd``).  All operands ``[B,H,S,D]``-shaped (any strides, head dim
+    contiguous), ``lse`` the forward's ``[B,H,Sq]`` fp32 LSE.  Returns gradients as ``[B,H,S,D]`` views of
+    ``[B,S,H,D]`` buffers, in ``grad_dtype`` (input dtype by default, or fp32)."""
+    B, H, Sq, D = q.shape
+    Sk = k.shape[2]
+    gdt = q.dtype if grad_dtype is None else grad_dtype
+    if dout.stride(3) != 1:
+        dout = dout.contiguous()
+    dq = torch.empty((B, Sq, H, D), dtype=gdt, device=q.device).permute(0, 2, 1, 3)
+    dk = torch.empty((B, Sk, H, D), dtype=gdt, device=q.device).permute(0, 2, 1, 3)
+    dv = torch.empty((B, Sk, H, D), dtype=gdt, device=q.device).permute(0, 2, 1, 3)
+    delta = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
+    a = _capi.PfaFa3BwdArgs()
+    a.size = C.sizeof(_capi.PfaFa3BwdArgs)
+    for name, t in (("q", q), ("k", k), ("v", v), ("o", out), ("dout", dout), ("dq", dq), ("dk", dk), ("dv", dv)):
+        setattr(a, name, t.data_ptr())
+        sb, sh, ss = _bhsd_strides(t)
+        pre = "do" if name == "dout" else name
+        setattr(a, f"{pre}_stride_b", sb); setattr(a, f"{pre}_stride_h", sh); setattr(a, f"{pre}_stride_s", ss)
+    if lse.shape != (B, H, Sq) or lse.dtype != torch.float32 or not lse.is_contiguous():
+        raise ValueError("lse must be contiguous fp32 [B, H, Sq]")
+    a.lse, a.delta = lse.data_ptr(), delta.data_ptr()
+    keep = [delta]
+    if seqlens_k is not None:
+        sl = torch.as_tensor(seqlens_k, dtype=torch.int32, device=q.device).contiguous()
+        a.seqlens_k = sl.data_ptr()
+        keep.append(sl)
+    a.B, a.H, a.Sq, a.Sk, a.D = B, H, Sq, Sk, D
+    a.dtype, a.dtype_grad, a.causal = _DT[q.dtype], _DT[gdt], 1 if causal else 0
+    a.softmax_scale = float(D ** -0.5 if softmax_scale is None else softmax_scale)
+    a.device_id = q.device.index if q.device.index is not None else torch.cuda.current_device()
+    stream = torch.cuda.current_stream(q.device)
+    st = _capi.load().pfa_fa3_bwd(C.byref(a), C.c_void_p(stream.cuda_stream))
+    if st in (-3, -4, -5, -6, -7, -10):
+        raise ValueError(f"pfa_fa3_bwd: {_capi.status_string(st)}")
+    _capi.check_status(st)
+    for t in keep:
+        t.record_stream(stream)
+    return dq, dk, dv
+
+
+class _FA3Function(torch.autograd.Function):
+    """Differentiable ``fa3_forward`` (causal / seqlens_k masks): saves q, k, v, o and the LSE."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, causal, seqlens_k, softmax_scale):
+        out, lse = fa3_forward(q, k, v, causal=causal, seqlens_k=seqlens_k, softmax_scale=softmax_scale, return_lse=True)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.causal, ctx.seqlens_k, ctx.softmax_scale = causal, seqlens_k, softmax_scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        dq, dk, dv = fa3_backward(q, k, v, out, dout, lse, causal=ctx.causal, seqlens_k=ctx.seqlens_k,
+                                  softmax_scale=ctx.softmax_scale)
+        return dq, dk, dv, None, None, None
+
+
+def fa3_attention(q, k, v, *, causal: bool = False, seqlens_k=None, softmax_scale: Optional[float] = None):
+    """Autograd-aware attention on ``[B,H,S,D]`` operands: forward + backward on the HIP kernels."""
+    return _FA3Function.apply(q, k, v, causal, seqlens_k, softmax_scale)

@@ -1,0 +1,115 @@
+"""GPU tests of the backward kernels (pfa_fa3_bwd) against autograd through the
+CPU oracle (fp32; the reference itself gets its gradients from autograd through the same eager math,
+tests/unit/test_flash_attention_3.py:137-160 of the reference only require that gradients exist).
+
+Tolerance: P and dS enter the MFMAs as bf16/fp16 (relative 2^-9 / 2^-12 per element), so gradients are compared
+with  |err| <= tol_rel * max|ref|  (tol_rel = 1.5e-2 bf16, 4e-3 fp16) and a cosine similarity >= 0.9995."""
+
+from __future__ import annotations
+
+import pytest
+import torch
+
+from photonic_flash_attention_amd import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+CASES = [
+    # B, H, Sq, Sk, D, causal, seqlens
+    (1, 2, 64, 64, 64, False, None),
+    (2, 2, 128, 128, 128, True, None),
+    (1, 3, 200, 333, 64, False, None),
+    (2, 2, 384, 384, 128, True, None),
+    (1, 2, 300, 300, 128, False, [257]),
+    (1, 4, 1024, 1024, 128, True, None),
+    (2, 1, 97, 513, 64, True, [513, 40]),
+]
+
+
+def _ref_grads(q, k, v, dout, causal, lens):
+    from oracle import fa3_oracle as orc
+    qf, kf, vf = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    out = orc.attention_bshd(qf, kf, vf, causal=causal, seqlens_k=lens)
+    out.backward(dout.float())
+    return out.detach(), qf.grad, kf.grad, vf.grad
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", CASES)
+def test_backward_matches_autograd_of_oracle(case, dtype):
+    from photonic_flash_attention_amd import ops
+    B, H, Sq, Sk, D, causal, lens = case
+    q, k, v = synth.qkv(B, H, Sq, Sk, D, 500 + Sq, dtype)
+    dout = torch.from_numpy(synth.normal_f32((B, Sq, H, D), 900 + Sk)).to(q.dtype)
+    _, rq, rk, rv = _ref_grads(q, k, v, dout, causal, lens)
+    qd, kd, vd, gd = (t.to(DEV).permute(0, 2, 1, 3) for t in (q, k, v, dout))
+    out, lse = ops.fa3_forward(qd, kd, vd, causal=causal, seqlens_k=lens, return_lse=True)
+    dq, dk, dv = ops.fa3_backward(qd, kd, vd, out, gd, lse, causal=causal, seqlens_k=lens, grad_dtype=torch.float32)
+    torch.cuda.synchronize()
+    tol = 1.5e-2 if dtype == "bf16" else 4e-3
+    for name, got, ref in (("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
+        got = got.permute(0, 2, 1, 3).cpu()
+        assert bool(torch.isfinite(got).all()), name
+        err = float((got - ref).abs().max())
+        scale = float(ref.abs().max())
+        cos = float(torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0))
+        assert err <= tol * scale + 1e-6, f"{name} {case} {dtype}: err {err:.3e} vs max {scale:.3e}"
+        assert cos >= 0.9995, f"{name} cosine {cos}"
+
+
+def test_module_is_differentiable_like_the_reference():
+    """tests/unit/test_flash_attention_3.py:137-160 of the reference: gradients exist, are non-zero, have the
+    parameter's shape -- here through FlashAttention3 (projections by autograd, core by the HIP kernels)."""
+    from photonic_flash_attention_amd import FlashAttention3
+    from oracle import fa3_oracle as orc
+    E, H = 256, 4
+    m = FlashAttention3(E, H, dtype=torch.bfloat16).to(DEV).train()
+    x = torch.from_numpy(synth.normal_f32((2, 192, E), 77)).to(DEV, torch.bfloat16).requires_grad_(True)
+    out, w = m(x, is_causal=True)
+    assert w is None and out.requires_grad
+    out.float().square().mean().backward()
+    assert x.grad is not None and x.grad.shape == x.shape and float(x.grad.float().abs().sum()) > 0
+    for n_, p_ in m.named_parameters():
+        assert p_.grad is not None and p_.grad.shape == p_.shape and bool(torch.isfinite(p_.grad.float()).all()), n_
+    # numbers: same module in fp32 on the CPU with the oracle core under autograd
+    sd = {k_: v_.detach().float().cpu().clone().requires_grad_(True) for k_, v_ in m.state_dict().items()}
+    xc = x.detach().float().cpu().requires_grad_(True)
+    ref = orc.module_forward(sd, H, xc, mask=orc.causal_mask(192, 192))
+    ref.square().mean().backward()
+    gx = x.grad.float().cpu()
+    assert float((gx - xc.grad).abs().max()) <= 0.05 * float(xc.grad.abs().max()) + 1e-6
+    gw = m.qkv_proj.weight.grad.float().cpu()
+    cos = float(torch.nn.functional.cosine_similarity(gw.flatten(), sd["qkv_proj.weight"].grad.flatten(), dim=0))
+    assert cos >= 0.995
+
+
+def test_backward_is_bitwise_reproducible():
+    from photonic_flash_attention_amd import ops
+    q, k, v = (t.to(DEV).permute(0, 2, 1, 3) for t in synth.qkv(1, 4, 640, 640, 128, 6, "bf16"))
+    g = torch.from_numpy(synth.normal_f32((1, 640, 4, 128), 7)).to(DEV, torch.bfloat16).permute(0, 2, 1, 3)
+    out, lse = ops.fa3_forward(q, k, v, causal=True, return_lse=True)
+    a = ops.fa3_backward(q, k, v, out, g, lse, causal=True)
+    b = ops.fa3_backward(q, k, v, out, g, lse, causal=True)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_backward_matches_reference_autograd_golden():
+    """dq/dk/dv of the REAL reference (autograd through its eager core, tests/golden g8_*) vs the HIP backward."""
+    from conftest import golden_inputs, golden_names, load_golden
+    from photonic_flash_attention_amd import ops
+    names = golden_names("grad")
+    assert names
+    for name in names:
+        meta, arr = load_golden(name)
+        q, k, v = golden_inputs(meta)
+        dout = torch.from_numpy(synth.normal_f32((meta["B"], meta["Sq"], meta["H"], meta["D"]), meta["dout_seed"])).to(torch.bfloat16)
+        qd, kd, vd, gd = (t.to(DEV).permute(0, 2, 1, 3) for t in (q, k, v, dout))
+        out, lse = ops.fa3_forward(qd, kd, vd, causal=meta["causal"], return_lse=True)
+        grads = ops.fa3_backward(qd, kd, vd, out, gd, lse, causal=meta["causal"], grad_dtype=torch.float32)
+        for got, key in zip(grads, ("dq", "dk", "dv")):
+            ref = torch.from_numpy(arr[key])
+            got = got.permute(0, 2, 1, 3).cpu()
+            err, scale = float((got - ref).abs().max()), float(ref.abs().max())
+            print(f"{name} {key}: max-abs {err:.3e} (max |ref| {scale:.3e})")
+            assert err <= 1.5e-2 * scale, (name, key, err, scale)

@@ -167,56 +167,18 @@ def test_hybrid_returns_raw_tuple_and_counts_gpu_samples():
     assert st["gpu_samples"] == 12 and st["photonic_samples"] == 0 and st["total_requests"] == 12
 
 
-def test_no_grad_required_and_dropout_rules():
+def test_grad_mode_and_dropout_rules():
     from photonic_flash_attention_amd import FlashAttention3
     m = FlashAttention3(128, 2, dropout=0.1, dtype=torch.bfloat16).to(DEV)
     x = torch.zeros(1, 16, 128, device=DEV, dtype=torch.bfloat16)
-    with pytest.raises(RuntimeError, match="no_grad"):
-        m(x)
     m.train()
+    with pytest.raises(NotImplementedError):           # training-mode attention dropout: not on the HIP path
+        m(x)
     with torch.no_grad(), pytest.raises(NotImplementedError):
         m(x)
     m.eval()
+    assert m(x)[0].requires_grad                        # eval + autograd: differentiable through pfa_fa3_bwd
+    with pytest.raises(NotImplementedError):           # ... but not with an explicit mask or weights
+        m(x, attention_mask=torch.ones(1, 16, device=DEV))
     with torch.no_grad():
-        assert m(x)[0].shape == x.shape                               # dropout is a no-op in eval (:174-175)
-
-
-def test_cli_benchmark_schema(tmp_path):
-    """Counterpart of the reference's `photonic-benchmark` (cli.py:20-145): same flags, same result keys."""
-    import json
-    from photonic_flash_attention_amd import cli
-    out = tmp_path / "bench.json"
-    args = cli._parser().parse_args(["--seq-lengths", "128", "640", "--batch-sizes", "2", "--embed-dim", "256",
-                                     "--num-heads", "4", "--num-iterations", "3", "--output", str(out)])
-    res = cli.benchmark(args)
-    ref_keys = {"batch_size", "seq_length", "embed_dim", "num_heads", "avg_latency_ms", "std_latency_ms",
-                "min_latency_ms", "max_latency_ms", "tokens_per_sec", "last_device_used", "gpu_calls",
-                "photonic_calls", "photonic_usage_ratio"}
-    assert len(res) == 2 and all(ref_keys <= set(r) for r in res)
-    assert all(r["last_device_used"] == "gpu" and r["attn_tflops"] > 0 for r in res)
-    data = json.loads(out.read_text())
-    assert set(data) == {"benchmark_info", "results"} and {"version", "timestamp", "device_info", "config"} <= set(data["benchmark_info"])
-
-
-def test_convert_to_photonic_transformer_layer_on_gpu():
-    """Converted nn.TransformerEncoderLayer (bf16, our kernel) vs the ORIGINAL torch layer in fp32 on the CPU."""
-    import torch.nn as nn
-    from photonic_flash_attention_amd import convert_to_photonic
-    torch.manual_seed(1)
-    layer = nn.TransformerEncoderLayer(d_model=512, nhead=4, dim_feedforward=1024, dropout=0.0, batch_first=True).eval()
-    x = torch.from_numpy(synth.normal_f32((2, 300, 512), 21))
-    pad = torch.zeros(2, 300, dtype=torch.bool)
-    pad[1, 250:] = True
-    causal = nn.Transformer.generate_square_subsequent_mask(300)
-    conv, rep = convert_to_photonic(layer, dtype=torch.bfloat16)
-    assert rep.converted_layers == ["self_attn"]
-    conv = conv.to(DEV).to(torch.bfloat16)
-    with torch.no_grad():
-        for kw in (dict(), dict(src_key_padding_mask=pad), dict(src_mask=causal, is_causal=True)):
-            want = layer(x, **kw)
-            kw_dev = {k_: (v_.to(DEV) if torch.is_tensor(v_) else v_) for k_, v_ in kw.items()}
-            got = conv(x.to(DEV, torch.bfloat16), **kw_dev).float().cpu()
-            keep = ~pad if "src_key_padding_mask" in kw else torch.ones(2, 300, dtype=torch.bool)
-            err = float((got - want)[keep].abs().max())
-            assert err <= 0.12, (list(kw), err)            # bf16 end-to-end layer (LayerNorm + FFN in bf16)
-            assert float((got - want)[keep].abs().mean()) <= 0.012
+        assert m(x)[0].shape == x.shape                 # dropout is a no-op in eval (:174-175)

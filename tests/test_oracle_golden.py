@@ -92,3 +92,18 @@ def test_generator_moments_and_exactness():
     b = synth.round_to_bf16_bits(x)
     t = torch.from_numpy(x).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
     assert np.array_equal(b, t)
+
+
+@pytest.mark.parametrize("name", golden_names("grad"))
+def test_oracle_autograd_matches_reference_autograd(name):
+    """The backward oracle = autograd through our restatement; pinned by gradients of the REAL reference."""
+    meta, arr = load_golden(name)
+    q, k, v = golden_inputs(meta)
+    dout = torch.from_numpy(synth.normal_f32((meta["B"], meta["Sq"], meta["H"], meta["D"]), meta["dout_seed"])).to(torch.bfloat16)
+    qf, kf, vf = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    out = orc.attention_bshd(qf, kf, vf, causal=meta["causal"])
+    (out * dout.float()).sum().backward()
+    assert float((out.detach() - torch.from_numpy(arr["out"])).abs().max()) <= ORACLE_TOL
+    for g, key in ((qf.grad, "dq"), (kf.grad, "dk"), (vf.grad, "dv")):
+        ref = torch.from_numpy(arr[key])
+        assert float((g - ref).abs().max()) <= 2e-5 * max(1.0, float(ref.abs().max())), key
