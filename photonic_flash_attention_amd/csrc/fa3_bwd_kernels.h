@@ -73,58 +73,90 @@ struct TileDma {
     static constexpr int TILE_BYTES = BLOCK_N * D * 2;
     static constexpr int PIECES = TILE_BYTES / 1024;
     static constexpr int PPW = PIECES / NW;
-    uint32_t off_a[PPW], off_b[PPW];     // per-lane byte offsets inside the two source slabs
+    static constexpr int ROWS_PER_T = (D == 128) ? 4 * NW : 8 * NW;   // source rows between a wave's pieces
+    uint32_t off_a, off_b;               // per-lane byte offsets inside the two source slabs (piece 0)
     __device__ __forceinline__ void init(int wave, int lane, int64_t stride_a, int64_t stride_b) {
         const int R0 = 4 * wave + (lane >> 4);
         const int sw = ((R0 & 3) << 2) | ((R0 >> 2) & 3);
         const int cc = (lane & 15) ^ sw;
-#pragma unroll
-        for (int t = 0; t < PPW; ++t) {
-            int row, col;
-            if constexpr (D == 128) {
-                row = R0 + 4 * NW * t;
-                col = cc * 8;
-            } else {
-                row = 2 * (R0 + 4 * NW * t) + (cc >> 3);
-                col = (cc & 7) * 8;
-            }
-            off_a[t] = (uint32_t)(row * (int)stride_a + col) * 2u;
-            off_b[t] = (uint32_t)(row * (int)stride_b + col) * 2u;
+        int row, col;
+        if constexpr (D == 128) {
+            row = R0;
+            col = cc * 8;
+        } else {
+            row = 2 * R0 + (cc >> 3);
+            col = (cc & 7) * 8;
         }
+        off_a = (uint32_t)(row * (int)stride_a + col) * 2u;
+        off_b = (uint32_t)(row * (int)stride_b + col) * 2u;
     }
     // tile j of slab A -> LDS at lds_a, of slab B -> lds_b (rows past `rows` read as zeros)
     __device__ __forceinline__ void issue(int wave, int j, const char* base_a, int64_t stride_a, int64_t slab_a,
                                           uint32_t lds_a, const char* base_b, int64_t stride_b, int64_t slab_b,
                                           uint32_t lds_b) const {
-        const int64_t sa = (int64_t)j * BLOCK_N * stride_a * 2, sb = (int64_t)j * BLOCK_N * stride_b * 2;
-        const srd_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(base_a + sa), 0, (int)max((int64_t)0, slab_a - sa), 0x00020000);
-        const srd_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(base_b + sb), 0, (int)max((int64_t)0, slab_b - sb), 0x00020000);
+        // one descriptor per piece (SALU only): the uniform row step lives in the base so that the range check still
+        // sees it (an SGPR soffset would bypass the check and ragged tails would read past the slab)
+        const int64_t step_a = (int64_t)ROWS_PER_T * stride_a * 2, step_b = (int64_t)ROWS_PER_T * stride_b * 2;
 #pragma unroll
         for (int t = 0; t < PPW; ++t) {
-            lds_dma16_buf(ra, off_a[t], lds_a + (wave + NW * t) * 1024);
-            lds_dma16_buf(rb, off_b[t], lds_b + (wave + NW * t) * 1024);
+            const int64_t sa = (int64_t)j * BLOCK_N * stride_a * 2 + t * step_a;
+            const int64_t sb = (int64_t)j * BLOCK_N * stride_b * 2 + t * step_b;
+            const srd_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(base_a + sa), 0, (int)max((int64_t)0, slab_a - sa), 0x00020000);
+            const srd_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(base_b + sb), 0, (int)max((int64_t)0, slab_b - sb), 0x00020000);
+            lds_dma16_buf(ra, off_a, lds_a + (wave + NW * t) * 1024);
+            lds_dma16_buf(rb, off_b, lds_b + (wave + NW * t) * 1024);
         }
     }
 };
 
-// per-lane read offsets inside one tile image
-template <typename T, int D>
+// compile-time loop: f(IC<0>{}), f(IC<1>{}), ... f(IC<N-1>{})
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(IC<I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+// per-lane read offsets inside one tile image.  LEAN (D = 128 only): keep one row base and two transposed-read
+// bases and derive the others with one v_xor each at the point of use -- the swizzle is an XOR on the chunk bits, so
+// chunk 2ks+h of row r sits at base(r, h) ^ (ks << 5) and d-block db at base ^ (db << 6).  Saves 13 VGPRs in the
+// dK/dV kernel, whose budget is 256 for two workgroups per CU.  (volatile asm: must not be hoisted back out.)
+template <int C>
+__device__ __forceinline__ uint32_t xor_const(uint32_t x) {
+    if constexpr (C == 0) return x;
+    uint32_t o;
+    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(o) : "i"(C), "v"(x));
+    return o;
+}
+template <typename T, int D, bool LEAN = false>
 struct TileRead {
+    static_assert(!LEAN || D == 128, "lean addressing relies on one row per 256-byte LDS row");
     static constexpr int KS = D / 16, DB = D / 32, NS2 = (D == 128) ? 1 : 2;
-    uint32_t row_off[KS];            // row read (32 rows r, chunk 2ks+h), +HALF_TILE for rows 32..63
-    uint32_t tr_off[NS2][DB][2];     // transposed read (see fa3_fwd_kernel.h)
+    uint32_t row_off[LEAN ? 1 : KS];                              // row read (32 rows r, chunk 2ks+h), +HALF_TILE for rows 32..63
+    uint32_t tr_off[LEAN ? 1 : NS2][LEAN ? 1 : DB][2];            // transposed read (see fa3_fwd_kernel.h)
     __device__ __forceinline__ void init(int lane, uint32_t base) {
         const int r = lane & 31, h = lane >> 5;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) row_off[ks] = base + tile_off<D>(r, 2 * ks + h);
+        for (int ks = 0; ks < (LEAN ? 1 : KS); ++ks) row_off[ks] = base + tile_off<D>(r, 2 * ks + h);
         const int g1 = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
 #pragma unroll
-        for (int s2 = 0; s2 < NS2; ++s2)
+        for (int s2 = 0; s2 < (LEAN ? 1 : NS2); ++s2)
 #pragma unroll
-            for (int db = 0; db < DB; ++db)
+            for (int db = 0; db < (LEAN ? 1 : DB); ++db)
 #pragma unroll
                 for (int hi = 0; hi < 2; ++hi)
                     tr_off[s2][db][hi] = base + tile_off<D>(16 * s2 + 4 * h + tq + 8 * hi, db * 4 + 2 * g1 + (tp >> 1)) + 8 * (tp & 1);
+    }
+    template <int KSI>
+    __device__ __forceinline__ uint32_t row_at() const {
+        if constexpr (LEAN) return xor_const<(KSI << 5)>(row_off[0]);
+        else return row_off[KSI];
+    }
+    template <int S2, int DBI, int HI>
+    __device__ __forceinline__ uint32_t tr_at() const {
+        if constexpr (LEAN) return xor_const<(DBI << 6)>(tr_off[0][0][HI]);
+        else return tr_off[S2][DBI][HI];
     }
 };
 
@@ -289,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
 // ---------------------------------------------------------------------------------------------------------------
 // dK, dV: key-stationary.  Workgroup = 4 waves x 32 keys = 128 keys; LDS stage = [Q image | dO image] (64 rows).
 template <typename T, int D, bool CAUSAL, typename OT>
-__global__ __launch_bounds__(256, 1) void fa3_bwd_dkdv_kernel(const BwdParams p) {
+__global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p) {
     using E = Elem<T>;
     using v8 = typename E::v8;
     using v4 = typename E::v4;
@@ -353,7 +385,7 @@ __global__ __launch_bounds__(256, 1) void fa3_bwd_dkdv_kernel(const BwdParams p)
 
     TileDma<D, NW> dma;
     dma.init(wave, lane, p.q_ss, p.do_ss);
-    TileRead<T, D> rq;
+    TileRead<T, D, D == 128> rq;
     rq.init(lane, smem_base);
 
     f32x16 dk[DB], dv[DB];                   // dK^T[d][key], dV^T[d][key]
@@ -384,54 +416,56 @@ __global__ __launch_bounds__(256, 1) void fa3_bwd_dkdv_kernel(const BwdParams p)
                 }
             }
         }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const v8 qa = *(const lds_v8*)(uintptr_t)(rq.row_off[ks] + BOFF + HOFF);
-            const v8 ga = *(const lds_v8*)(uintptr_t)(rq.row_off[ks] + BOFF + TILE_BYTES + HOFF);
+        static_for<KS>([&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value;
+            const uint32_t ro = rq.template row_at<ks>();
+            const v8 qa = *(const lds_v8*)(uintptr_t)(ro + BOFF + HOFF);
+            const v8 ga = *(const lds_v8*)(uintptr_t)(ro + BOFF + TILE_BYTES + HOFF);
             s = E::mfma(qa, kf[ks], s);          // S[q][key] - lse/scale
             dpv = E::mfma(ga, vf[ks], dpv);      // dP[q][key] - delta
-        }
-        v8 pb[2], dsb[2];
+        });
+        // dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]   (16 query rows per s2)
+        static_for<2>([&](auto s2c) {
+            constexpr int s2 = decltype(s2c)::value;
+            constexpr int S2I = (D == 128) ? 0 : s2;
+            constexpr int koffs = BOFF + HOFF + ((D == 128) ? s2 * 16 * 256 : 0);
+            v8 pb, dsb;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int qi = q_base + (e & 3) + 8 * (e >> 2) + 4 * h;
-            bool ok = key_ok;
-            if (CAUSAL) ok = ok && (my_key <= qi);
-            const float pe = ok ? fast_exp2(s[e] * c) : 0.f;      // exp(scale*S - lse); rows staged as -inf give 0
-            const float de = pe * dpv[e];
-            pb[e >> 3][e & 7] = (T)pe;
-            dsb[e >> 3][e & 7] = (T)de;
-        }
-        // dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            constexpr int S2I = (D == 128) ? 0 : 1;
-            const int koffs = BOFF + HOFF + ((D == 128) ? s2 * 16 * 256 : 0);
-#pragma unroll
-            for (int db = 0; db < DB; ++db) {
+            for (int e8 = 0; e8 < 8; ++e8) {
+                const int e = 8 * s2 + e8;
+                const int qi = q_base + (e & 3) + 8 * (e >> 2) + 4 * h;
+                bool ok = key_ok;
+                if (CAUSAL) ok = ok && (my_key <= qi);
+                const float pe = ok ? fast_exp2(s[e] * c) : 0.f;      // exp(scale*S - lse); rows staged as -inf give 0
+                pb[e8] = (T)pe;
+                dsb[e8] = (T)(pe * dpv[e]);
+            }
+            static_for<DB>([&](auto dbc) {
+                constexpr int db = decltype(dbc)::value;
+                const uint32_t t0 = rq.template tr_at<S2I, db, 0>(), t1 = rq.template tr_at<S2I, db, 1>();
                 v8 a;
                 {
-                    const v4 lo = E::tr_read((const lds_char*)(uintptr_t)(rq.tr_off[s2 * S2I][db][0] + koffs + TILE_BYTES));
-                    const v4 hi4 = E::tr_read((const lds_char*)(uintptr_t)(rq.tr_off[s2 * S2I][db][1] + koffs + TILE_BYTES));
+                    const v4 lo = E::tr_read((const lds_char*)(uintptr_t)(t0 + koffs + TILE_BYTES));
+                    const v4 hi4 = E::tr_read((const lds_char*)(uintptr_t)(t1 + koffs + TILE_BYTES));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         a[e] = lo[e];
                         a[4 + e] = hi4[e];
                     }
                 }
-                dv[db] = E::mfma(a, pb[s2], dv[db]);
+                dv[db] = E::mfma(a, pb, dv[db]);
                 {
-                    const v4 lo = E::tr_read((const lds_char*)(uintptr_t)(rq.tr_off[s2 * S2I][db][0] + koffs));
-                    const v4 hi4 = E::tr_read((const lds_char*)(uintptr_t)(rq.tr_off[s2 * S2I][db][1] + koffs));
+                    const v4 lo = E::tr_read((const lds_char*)(uintptr_t)(t0 + koffs));
+                    const v4 hi4 = E::tr_read((const lds_char*)(uintptr_t)(t1 + koffs));
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         a[e] = lo[e];
                         a[4 + e] = hi4[e];
                     }
                 }
-                dk[db] = E::mfma(a, dsb[s2], dk[db]);
-            }
-        }
+                dk[db] = E::mfma(a, dsb, dk[db]);
+            });
+        });
     };
     auto step = [&](auto bufc, int j) {
         constexpr int BUF = decltype(bufc)::value;
