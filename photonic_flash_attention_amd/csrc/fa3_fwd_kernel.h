@@ -99,6 +99,39 @@ __device__ __forceinline__ uint32_t tile_off(uint32_t key, uint32_t ch) {
     return R * 256u + ((c ^ sw) << 4);
 }
 
+// Row maximum over one 16-register S block as ONE asm statement: hipcc puts an s_nop between consecutive
+// single-instruction asm statements that depend on each other (15 per tile), and the VALU issue port -- not the
+// MFMA pipe -- is what this kernel runs out of (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost').
+__device__ __forceinline__ float max16_first(const f32x16& a) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3\n\t"
+        "v_max3_f32 %0, %0, %4, %5\n\t"
+        "v_max3_f32 %0, %0, %6, %7\n\t"
+        "v_max3_f32 %0, %0, %8, %9\n\t"
+        "v_max3_f32 %0, %0, %10, %11\n\t"
+        "v_max3_f32 %0, %0, %12, %13\n\t"
+        "v_max3_f32 %0, %0, %14, %15\n\t"
+        "v_max_f32 %0, %0, %16"
+        : "=&v"(r)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]),
+          "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15]));
+    return r;
+}
+__device__ __forceinline__ float max16_next(float r, const f32x16& a) {
+    asm("v_max3_f32 %0, %0, %1, %2\n\t"
+        "v_max3_f32 %0, %0, %3, %4\n\t"
+        "v_max3_f32 %0, %0, %5, %6\n\t"
+        "v_max3_f32 %0, %0, %7, %8\n\t"
+        "v_max3_f32 %0, %0, %9, %10\n\t"
+        "v_max3_f32 %0, %0, %11, %12\n\t"
+        "v_max3_f32 %0, %0, %13, %14\n\t"
+        "v_max3_f32 %0, %0, %15, %16"
+        : "+&v"(r)
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]),
+          "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15]));
+    return r;
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // One v_max3_f32.  fmaxf() on MFMA results makes hipcc emit a canonicalising v_max_f32 x,x per operand
@@ -113,6 +146,12 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
 __device__ __forceinline__ float row_pair_max(float x) {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// same, without the canonicalising v_max x,x hipcc adds around fmaxf (s_nop 1: VALU write -> permlane read)
+__device__ __forceinline__ float row_pair_max_asm(float x) {
+    float t;
+    asm("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1" : "+v"(x), "=&v"(t));
+    return x;
 }
 __device__ __forceinline__ float row_pair_sum(float x) {
     auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -141,7 +180,7 @@ constexpr int ABL_NO_QK = 1 << 18;        // skip the QK^T MFMAs and K reads (S 
 constexpr int ABL_NO_EXP = 1 << 19;       // softmax without the v_exp (p = fma result)
 constexpr int VAR_ALTPRIO = 32768; // s_setprio alternates between the wave halves every tile (with VAR_STAGE2: each half wins once per barrier)
 constexpr int VAR_DMA4 = 16384;    // only waves 0..NW/2-1 (the older half, which waits at the barrier anyway) issue the LDS-DMA
-constexpr int VAR_W4 = 8192;       // 4 waves x 64 rows, one wave per SIMD (fa3_fwd_w4_kernel.h)
+constexpr int VAR_DIET = 8192;     // VALU diet: row max as one asm block (no s_nop between), opaque LDS addresses (no per-tile v_add), no packed adds
 constexpr int VAR_YPRIO = 2048;    // static s_setprio 1 for the younger wave half (waves NW/2..NW-1)
 constexpr int VAR_LATEDMA = 4096;  // waves NW/2.. issue their DMA pieces after QK^T instead of at the top of the tile
 constexpr int VAR_STAGGER = 1024;  // waves 4-7 one phase behind waves 0-3 (fa3_fwd_stagger_kernel.h)
@@ -152,7 +191,7 @@ constexpr int VAR_BUFDMA = 64;     // LDS-DMA by buffer_load ... lds: SRD rebuil
 constexpr int VAR_PIPE = 32;       // software-pipelined half-tile schedule (fa3_fwd_pipe_kernel.h)
 constexpr int VAR_NW4 = 16;        // 4-wave workgroups of 128 Q rows, two resident per CU (independent barriers)
 constexpr int VAR_GLDS = 8;        // K/V tiles by LDS-DMA (global_load_lds_dwordx4), swizzle on the source address
-constexpr int VAR_DEFAULT = VAR_DEFER_MAX | VAR_SCHED | VAR_GLDS | VAR_BUFDMA;
+constexpr int VAR_DEFAULT = VAR_DEFER_MAX | VAR_SCHED | VAR_GLDS | VAR_BUFDMA | VAR_DIET;
 
 template <int N> struct IC { static constexpr int value = N; };
 
@@ -366,6 +405,11 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
     uint32_t koff[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) koff[ks] = smem_base + tile_off<D>(r, 2 * ks + h);   // absolute LDS address
+    // opaque to the optimiser: otherwise it keeps row and chunk parts apart and re-adds them every tile (25 v_add_u32)
+    if constexpr (VAR & VAR_DIET) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(koff[ks]));
+    }
     // V transposed read (kb, s2, db, hi8): lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3 of the
     // 4-key x 16-d block at key0 = 32 kb + 16 s2 + 4 h (+8), d0 = 32 db + 16 ((lane>>4)&1)
     const int g1 = (lane >> 4) & 1;
@@ -379,7 +423,10 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
         for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int hi = 0; hi < 2; ++hi)
+            {
                 voff[s2][db][hi] = smem_base + tile_off<D>(16 * s2 + 4 * h + tq + 8 * hi, db * 4 + 2 * g1 + (tp >> 1)) + 8 * (tp & 1);
+                if constexpr (VAR & VAR_DIET) asm volatile("" : "+v"(voff[s2][db][hi]));
+            }
 
     f32x16 o[DB];
 #pragma unroll
@@ -396,6 +443,7 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
     for (int e = 0; e < 8; ++e) ones[e] = (T)1.0f;
     const float c = p.scale_log2;
     const float thr = (VAR & VAR_DEFER_MAX) ? 8.0f / c : 0.0f;   // raw-score headroom before a rescale
+    float m_thr = -1e30f, mc = -1e30f * c;                       // m_run + thr and m_run * c, updated with m_run
 
     unsigned long long st_qk_end = 0;
     // ---- one K/V tile: S^T = K Q^T, online softmax, O^T += V^T P^T -------------------------------------------
@@ -510,21 +558,29 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
 
         if constexpr (!(VAR & ABL_NO_SOFTMAX)) {
         // online softmax (flash_attention_3.py:239-246); a row lives in lanes (l, l^32)
-        float mx = max3(s[0][0], s[1][0], s[0][1]);
-        mx = max3(mx, s[1][1], s[0][2]);
+        float mx;
+        if constexpr (VAR & VAR_DIET) {
+            mx = max16_first(s[0]);
+            mx = max16_next(mx, s[1]);
+        } else {
+            mx = max3(s[0][0], s[1][0], s[0][1]);
+            mx = max3(mx, s[1][1], s[0][2]);
 #pragma unroll
-        for (int e = 2; e < 16; e += 2) {
-            mx = max3(mx, s[1][e], s[0][e + 1]);
-            if (e + 2 < 16) mx = max3(mx, s[1][e + 1], s[0][e + 2]);
-            else mx = fmaxf(mx, s[1][e + 1]);
+            for (int e = 2; e < 16; e += 2) {
+                mx = max3(mx, s[1][e], s[0][e + 1]);
+                if (e + 2 < 16) mx = max3(mx, s[1][e + 1], s[0][e + 2]);
+                else mx = fmaxf(mx, s[1][e + 1]);
+            }
         }
-        mx = row_pair_max(mx);
+        mx = (VAR & VAR_DIET) ? row_pair_max_asm(mx) : row_pair_max(mx);
         // rescale only when some row's max outgrew the headroom (thr = 0: whenever any max moved -> exact
         // lazy rescale; thr > 0: exponentials may reach 2^8, harmless in fp32/bf16 and cancelled by l)
-        if (__builtin_amdgcn_ballot_w64(mx > m_run + thr) != 0) {
+        if (__builtin_amdgcn_ballot_w64(mx > m_thr) != 0) {
             const float m_new = fmaxf(m_run, mx);
             const float alpha = fast_exp2((m_run - m_new) * c);
             m_run = m_new;
+            m_thr = m_new + thr;
+            mc = m_new * c;
             l_run *= alpha;
             if (VAR & VAR_LSUM) {
 #pragma unroll
@@ -535,7 +591,6 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
 #pragma unroll
                 for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
         }
-        const float mc = m_run * c;
         float psum0 = 0.f, psum1 = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -548,6 +603,7 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
             }
             if (!(VAR & VAR_LSUM)) {
                 psum0 += s[0][e];
+                if constexpr (VAR & VAR_DIET) asm volatile("" : "+v"(psum0));   // keeps SLP from pairing the sums into v_pk_add_f32
                 psum1 += s[1][e];
             }
         }

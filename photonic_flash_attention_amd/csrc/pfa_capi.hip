@@ -38,10 +38,6 @@ Variant mk(const char* tn, const char* on) {
     if (VAR & pfa::VAR_STAGGER) v.lds_bytes = 5 * pfa::BLOCK_N * D * 2;   // K ring 2 + V ring 3
     v.nthreads = ((VAR & pfa::VAR_NW4) ? 4 : 8) * 64;
     v.block_m = v.nthreads / 2;
-    if (VAR & pfa::VAR_W4) {
-        v.nthreads = 256;
-        v.block_m = 256;
-    }
     return v;
 }
 
@@ -109,6 +105,7 @@ Variant pick(const pfa_fa3_args* a) {
             case 39: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_PF8 | pfa::VAR_SETPRIO>(causal);
             case 31: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_DMA>(causal);
             case 32: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_DMA | pfa::ABL_NO_BARRIER>(causal);
+            case 40: return exp_variant<pfa::VAR_DEFAULT & ~pfa::VAR_DIET>(causal);                           // before the VALU diet (reference for A/B)
             case 14: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_QKIL>(causal);
             case 15: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_PF8>(causal);
             case 17: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_QKIL | pfa::VAR_PF8>(causal);
