@@ -68,6 +68,14 @@ __global__ __launch_bounds__(256) void fa3_bwd_delta_kernel(const BwdParams p) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Shared tile machinery: 64-row x D tile images (two per stage), LDS-DMA by buffer descriptor, swizzled.
+// raw-buffer descriptor whose inputs are provably wave-uniform (readfirstlane folds away when they already are)
+__device__ __forceinline__ srd_t uniform_srd(const char* base, uint32_t bytes) {
+    const uint64_t a = (uint64_t)(uintptr_t)base;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)hi << 32) | lo), 0,
+                                             (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
 template <int D, int NW>
 struct TileDma {
     static constexpr int TILE_BYTES = BLOCK_N * D * 2;
@@ -90,19 +98,22 @@ struct TileDma {
         off_a = (uint32_t)(row * (int)stride_a + col) * 2u;
         off_b = (uint32_t)(row * (int)stride_b + col) * 2u;
     }
-    // tile j of slab A -> LDS at lds_a, of slab B -> lds_b (rows past `rows` read as zeros)
+    // tile j of slab A -> LDS at lds_a, of slab B -> lds_b (rows past the slab read as zeros).  Slabs are < 2 GiB
+    // (pfa_fa3_bwd checks it), so offsets and remaining-byte counts are 32-bit SALU work.
     __device__ __forceinline__ void issue(int wave, int j, const char* base_a, int64_t stride_a, int64_t slab_a,
                                           uint32_t lds_a, const char* base_b, int64_t stride_b, int64_t slab_b,
                                           uint32_t lds_b) const {
         // one descriptor per piece (SALU only): the uniform row step lives in the base so that the range check still
         // sees it (an SGPR soffset would bypass the check and ragged tails would read past the slab)
-        const int64_t step_a = (int64_t)ROWS_PER_T * stride_a * 2, step_b = (int64_t)ROWS_PER_T * stride_b * 2;
+        const uint32_t step_a = (uint32_t)(ROWS_PER_T * 2) * (uint32_t)stride_a, step_b = (uint32_t)(ROWS_PER_T * 2) * (uint32_t)stride_b;
+        const uint32_t sa0 = (uint32_t)j * (uint32_t)(BLOCK_N * 2) * (uint32_t)stride_a;
+        const uint32_t sb0 = (uint32_t)j * (uint32_t)(BLOCK_N * 2) * (uint32_t)stride_b;
+        const uint32_t la = (uint32_t)slab_a, lb = (uint32_t)slab_b;
 #pragma unroll
         for (int t = 0; t < PPW; ++t) {
-            const int64_t sa = (int64_t)j * BLOCK_N * stride_a * 2 + t * step_a;
-            const int64_t sb = (int64_t)j * BLOCK_N * stride_b * 2 + t * step_b;
-            const srd_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(base_a + sa), 0, (int)max((int64_t)0, slab_a - sa), 0x00020000);
-            const srd_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(base_b + sb), 0, (int)max((int64_t)0, slab_b - sb), 0x00020000);
+            const uint32_t sa = sa0 + t * step_a, sb = sb0 + t * step_b;
+            const srd_t ra = uniform_srd(base_a + sa, la > sa ? la - sa : 0u);
+            const srd_t rb = uniform_srd(base_b + sb, lb > sb ? lb - sb : 0u);
             lds_dma16_buf(ra, off_a, lds_a + (wave + NW * t) * 1024);
             lds_dma16_buf(rb, off_b, lds_b + (wave + NW * t) * 1024);
         }
@@ -203,8 +214,12 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
     const float lse = p.lse[stat];
     const float delta = p.delta[stat];
     const bool dead = !(lse > -INFINITY) || my_q >= p.Sq;
-    const float lse2 = dead ? 0.f : lse * 1.4426950408889634f;
+    const float lse2 = dead ? INFINITY : lse * 1.4426950408889634f;   // dead rows: exp2(x - inf) = 0 without a select
     const float c = p.scale_log2;
+    f32x16 negdelta;                         // -delta of this lane's row in every register: the dP accumulator's start
+#pragma unroll
+    for (int e = 0; e < 16; ++e) negdelta[e] = -delta;
+    asm volatile("" : "+v"(negdelta));
 
     TileDma<D, NW> dma;
     dma.init(wave, lane, p.k_ss, p.v_ss);
@@ -223,33 +238,33 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                s[kb][e] = 0.f;
-                dp[kb][e] = 0.f;
-            }
+            for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const v8 ka = *(const lds_v8*)(uintptr_t)(rk.row_off[ks] + BOFF + kb * HALF_TILE);
                 const v8 va = *(const lds_v8*)(uintptr_t)(rk.row_off[ks] + BOFF + TILE_BYTES + kb * HALF_TILE);
-                s[kb] = E::mfma(ka, qf[ks], s[kb]);          // S^T[key][q]
-                dp[kb] = E::mfma(va, gf[ks], dp[kb]);        // dP^T[key][q]
+                s[kb] = E::mfma(ka, qf[ks], s[kb]);                            // S^T[key][q]
+                dp[kb] = E::mfma(va, gf[ks], ks == 0 ? negdelta : dp[kb]);     // dP^T[key][q] - delta[q]
             }
         }
-        const bool need_mask = (key_base + BLOCK_N > kv_len) || (CAUSAL && key_base + BLOCK_N - 1 > wave_q0);
+        // masks only where a tile crosses the diagonal or the key tail (wave-uniform, a real branch)
+        if ((key_base + BLOCK_N > kv_len) || (CAUSAL && key_base + BLOCK_N - 1 > wave_q0)) {
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = key_base + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    bool ok = key < kv_len;
+                    if (CAUSAL) ok = ok && (key <= my_q);
+                    s[kb][e] = ok ? s[kb][e] : -INFINITY;
+                }
+        }
         // dS^T = P^T o (dP^T - delta), P^T = exp2(c S^T - lse2)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float pe = fast_exp2(__builtin_fmaf(s[kb][e], c, -lse2));
-                if (need_mask) {
-                    const int key = key_base + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
-                    bool ok = key < kv_len;
-                    if (CAUSAL) ok = ok && (key <= my_q);
-                    pe = ok ? pe : 0.f;
-                }
-                s[kb][e] = dead ? 0.f : pe * (dp[kb][e] - delta);
-            }
+            for (int e = 0; e < 16; ++e) s[kb][e] = fast_exp2(__builtin_fmaf(s[kb][e], c, -lse2)) * dp[kb][e];
         // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -424,6 +439,14 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
             s = E::mfma(qa, kf[ks], s);          // S[q][key] - lse/scale
             dpv = E::mfma(ga, vf[ks], dpv);      // dP[q][key] - delta
         });
+        // causal: only a half that reaches above the diagonal of this wave's 32 keys needs the mask (wave-uniform branch).
+        // Keys past kv_len need none: a lane is a key, its column feeds only its own dK/dV, zeroed at the store.
+        if (CAUSAL && q_base < wave_k0 + 31) {
+            asm volatile("" ::: "memory");
+            const int t = my_key - q_base - 4 * h;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[e] = (t <= (e & 3) + 8 * (e >> 2)) ? s[e] : -INFINITY;
+        }
         // dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]   (16 query rows per s2)
         static_for<2>([&](auto s2c) {
             constexpr int s2 = decltype(s2c)::value;
@@ -433,10 +456,7 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
 #pragma unroll
             for (int e8 = 0; e8 < 8; ++e8) {
                 const int e = 8 * s2 + e8;
-                const int qi = q_base + (e & 3) + 8 * (e >> 2) + 4 * h;
-                bool ok = key_ok;
-                if (CAUSAL) ok = ok && (my_key <= qi);
-                const float pe = ok ? fast_exp2(s[e] * c) : 0.f;      // exp(scale*S - lse); rows staged as -inf give 0
+                const float pe = fast_exp2(s[e] * c);       // exp(scale*S - lse); rows staged as -inf and masked entries give 0
                 pb[e8] = (T)pe;
                 dsb[e8] = (T)(pe * dpv[e]);
             }
@@ -498,6 +518,15 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
     for (int j = t_first; j < nt; j += 2) {
         step(IC<0>{}, j);
         if (j + 1 < nt) step(IC<1>{}, j + 1);
+    }
+    if (!key_ok) {                              // keys in [kv_len, Sk): gradients are exactly zero
+#pragma unroll
+        for (int i = 0; i < DB; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                dk[i][e] = 0.f;
+                dv[i][e] = 0.f;
+            }
     }
     if (my_key < p.Sk) {
         OT* krow_o = (OT*)p.dk + (int64_t)b * p.dk_sb + (int64_t)hh * p.dk_sh + (int64_t)my_key * p.dk_ss;

@@ -67,6 +67,18 @@ template <> struct Elem<__bf16> {
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
     }
+    // TIMING-ONLY stand-in (ABL_MFMA16): the same MACs as two v_mfma_f32_16x16x32 on 8 of the 16 accumulator registers
+    static __device__ __forceinline__ f32x16 mfma16x2(v8 a, v8 b, f32x16 c) {
+        f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, c1, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            c[e] = c0[e];
+            c[4 + e] = c1[e];
+        }
+        return c;
+    }
     static __device__ __forceinline__ v4 tr_read(const lds_char* p) {
         return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) v4*)p);
     }
@@ -76,6 +88,17 @@ template <> struct Elem<_Float16> {
     using v4 = f16x4;
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x16 mfma16x2(v8 a, v8 b, f32x16 c) {
+        f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b, a, c1, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            c[e] = c0[e];
+            c[4 + e] = c1[e];
+        }
+        return c;
     }
     static __device__ __forceinline__ v4 tr_read(const lds_char* p) {
         typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 h4;
@@ -177,6 +200,7 @@ constexpr int VAR_PF8 = 1 << 21;          // QK^T: operand reads 8 deep instead 
 constexpr int ABL_NO_SOFTMAX = 1 << 16;   // P = bf16(S): no max, no exp, no row sum
 constexpr int ABL_NO_PV = 1 << 17;        // skip the PV MFMAs and V reads
 constexpr int ABL_NO_QK = 1 << 18;        // skip the QK^T MFMAs and K reads (S = stale registers)
+constexpr int ABL_MFMA16 = (int)(1u << 31); // every 32x32x16 MFMA replaced by two 16x16x32 (same MACs, half the accumulator traffic): DVFS probe
 constexpr int ABL_NO_EXP = 1 << 19;       // softmax without the v_exp (p = fma result)
 constexpr int VAR_ALTPRIO = 32768; // s_setprio alternates between the wave halves every tile (with VAR_STAGE2: each half wins once per barrier)
 constexpr int VAR_DMA4 = 16384;    // only waves 0..NW/2-1 (the older half, which waits at the barrier anyway) issue the LDS-DMA
@@ -428,6 +452,10 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
                 if constexpr (VAR & VAR_DIET) asm volatile("" : "+v"(voff[s2][db][hi]));
             }
 
+    auto MF = [](v8 a, v8 b, f32x16 acc) {
+        if constexpr (VAR & ABL_MFMA16) return E::mfma16x2(a, b, acc);
+        else return E::mfma(a, b, acc);
+    };
     f32x16 o[DB];
 #pragma unroll
     for (int i = 0; i < DB; ++i)
@@ -508,7 +536,7 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
                 asm volatile("" ::"v"(afr[i % PF]));
                 if (i + PF < NQK) afr[i % PF] = *(const lds_v8*)(kimg + koff[ks_of(i + PF)] + kb_of(i + PF) * HALF_TILE);
             } else {
-                s[kb_of(i)] = E::mfma(afr[i % (PF ? PF : 1)], qf[ks_of(i)], s[kb_of(i)]);
+                s[kb_of(i)] = MF(afr[i % (PF ? PF : 1)], qf[ks_of(i)], s[kb_of(i)]);
                 if (i + PF < NQK) afr[i % (PF ? PF : 1)] = *(const lds_v8*)(kimg + koff[ks_of(i + PF)] + kb_of(i + PF) * HALF_TILE);
             }
         }
@@ -644,7 +672,7 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
                         a[e] = lo[e];
                         a[4 + e] = hi4[e];
                     }
-                    o[db] = E::mfma(a, ph, o[db]);
+                    o[db] = MF(a, ph, o[db]);
                     if (SPLITP) o[db] = E::mfma(a, pl, o[db]);
                 }
             }

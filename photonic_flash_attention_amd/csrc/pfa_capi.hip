@@ -106,6 +106,8 @@ Variant pick(const pfa_fa3_args* a) {
             case 31: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_DMA>(causal);
             case 32: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_DMA | pfa::ABL_NO_BARRIER>(causal);
             case 40: return exp_variant<pfa::VAR_DEFAULT & ~pfa::VAR_DIET>(causal);                           // before the VALU diet (reference for A/B)
+            case 41: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_MFMA16>(causal);                          // timing only: 16x16x32 MFMAs
+            case 42: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV | pfa::ABL_NO_DMA | pfa::ABL_NO_BARRIER | pfa::ABL_MFMA16>(causal);   // var 29 with 16x16x32
             case 14: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_QKIL>(causal);
             case 15: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_PF8>(causal);
             case 17: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_QKIL | pfa::VAR_PF8>(causal);

@@ -13,12 +13,16 @@ ap.add_argument("--variants", default="0,1,2,3,4,5")
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--check", action="store_true")
+ap.add_argument("--data", default="randn", choices=["randn", "zeros", "const", "small"], help="operand data: DVFS probe (cdna guide: zero operands clock higher)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 variants = [int(x) for x in a.variants.split(",")]
 for name in a.configs.split(","):
     B, H, S, D, causal = CONFIGS[name]
     q, k, v = (torch.randn(B, S, H, D, device=dev, dtype=torch.float32).to(torch.bfloat16) for _ in range(3))
+    if a.data == "zeros": q, k, v = (torch.zeros_like(t) for t in (q, k, v))
+    elif a.data == "const": q, k, v = (torch.full_like(t, 0.5) for t in (q, k, v))
+    elif a.data == "small": q, k, v = ((t * 0.01).to(torch.bfloat16) for t in (q, k, v))
     out = torch.empty(B, S, H, D, device=dev, dtype=torch.bfloat16).permute(0, 2, 1, 3)
     qv, kv, vv = (t.permute(0, 2, 1, 3) for t in (q, k, v))
     fl = 4.0 * B * H * S * S * D / (2 if causal else 1)
