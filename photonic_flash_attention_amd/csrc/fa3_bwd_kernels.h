@@ -236,17 +236,32 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
         constexpr int BOFF = decltype(bufc)::value * BUF_BYTES;
         f32x16 s[2], dp[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[kb][e] = 0.f;
+        // 4 KS operand fragments (K, V alternating) through a PF-deep register ring, order pinned with
+        // sched_group_barrier: hipcc otherwise emits read -> wait -> MFMA on one 4-register buffer
+        constexpr int NOP = 4 * KS, PF = 4;
+        auto frag = [&](int i) {     // step i: kb = i / (2 KS), ks = (i / 2) % KS, K (even) or V (odd)
+            return *(const lds_v8*)(uintptr_t)(rk.row_off[(i >> 1) % KS] + BOFF + (i & 1) * TILE_BYTES + (i / (2 * KS)) * HALF_TILE);
+        };
+        v8 afr[PF];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const v8 ka = *(const lds_v8*)(uintptr_t)(rk.row_off[ks] + BOFF + kb * HALF_TILE);
-                const v8 va = *(const lds_v8*)(uintptr_t)(rk.row_off[ks] + BOFF + TILE_BYTES + kb * HALF_TILE);
-                s[kb] = E::mfma(ka, qf[ks], s[kb]);                            // S^T[key][q]
-                dp[kb] = E::mfma(va, gf[ks], ks == 0 ? negdelta : dp[kb]);     // dP^T[key][q] - delta[q]
-            }
+        for (int i = 0; i < PF; ++i) afr[i] = frag(i);
+#pragma unroll
+        for (int i = 0; i < NOP; ++i) {
+            const int kb = i / (2 * KS), ks = (i >> 1) % KS;
+            if ((i & 1) == 0) s[kb] = E::mfma(afr[i % PF], qf[ks], s[kb]);                                // S^T[key][q]
+            else dp[kb] = E::mfma(afr[i % PF], gf[ks], ks == 0 ? negdelta : dp[kb]);                        // dP^T[key][q] - delta[q]
+            if (i + PF < NOP) afr[i % PF] = frag(i + PF);
         }
+        __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+        for (int i = 0; i < NOP - PF; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
         // masks only where a tile crosses the diagonal or the key tail (wave-uniform, a real branch)
         if ((key_base + BLOCK_N > kv_len) || (CAUSAL && key_base + BLOCK_N - 1 > wave_q0)) {
             asm volatile("" ::: "memory");
@@ -431,6 +446,8 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
                 }
             }
         }
+        // (a pinned prefetch ring as in the dQ kernel costs 20 spilled registers here and doubles the run time: the two
+        //  workgroups per CU cover the read latency instead)
         static_for<KS>([&](auto ksc) {
             constexpr int ks = decltype(ksc)::value;
             const uint32_t ro = rq.template row_at<ks>();
