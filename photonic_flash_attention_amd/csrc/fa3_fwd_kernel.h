@@ -809,7 +809,28 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
     // ---- epilogue: normalise (flash_attention_3.py:250 does it per tile; once is equivalent) ------------
     const float l_tot = (VAR & VAR_LSUM) ? lacc[0] : row_pair_sum(l_run);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;   // fully masked row -> zeros (documented divergence)
-    if (my_q < p.Sq) {
+    if constexpr (sizeof(OT) == 2 && (VAR & VAR_DIET)) {
+        // 16-bit store: lanes l and l+32 hold the two 8-byte halves of every 16-byte column group of one row.  One
+        // v_permlane32_swap per dword pairs group k (even) with k+1 so that each lane owns 16 contiguous bytes:
+        // 8 dwordx4 stores per lane instead of 16 dwordx2 -- the tail is store-issue bound (cdna guide T21).
+        char* orow = (char*)((OT*)p.o + (int64_t)b * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)min(my_q, p.Sq - 1) * p.o_ss) + 16 * h;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                v4 wa, wb;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    wa[e] = (T)(o[db][4 * g + e] * inv);
+                    wb[e] = (T)(o[db][4 * g + 4 + e] * inv);
+                }
+                u32x2 a = __builtin_bit_cast(u32x2, wa), bq = __builtin_bit_cast(u32x2, wb);
+                auto r0 = __builtin_amdgcn_permlane32_swap(a[0], bq[0], false, false);
+                auto r1 = __builtin_amdgcn_permlane32_swap(a[1], bq[1], false, false);
+                u32x4 w = {r0[0], r1[0], r0[1], r1[1]};
+                if (my_q < p.Sq) *(u32x4*)(orow + 2 * (db * 32 + 8 * g)) = w;
+            }
+    } else if (my_q < p.Sq) {
         OT* orow = (OT*)p.o + (int64_t)b * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)my_q * p.o_ss;
 #pragma unroll
         for (int db = 0; db < DB; ++db)
@@ -828,6 +849,8 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
                     *(v4*)(orow + d) = w;
                 }
             }
+    }
+    if (my_q < p.Sq) {
         if (p.lse && h == 0) {
             const float lse = l_tot > 0.f ? (m_run * c + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f : -INFINITY;
             p.lse[((int64_t)b * p.H + hh) * p.Sq + my_q] = lse;
