@@ -177,6 +177,11 @@ typedef struct pfa_fa3_bwd_args {
     int32_t causal;
     float   softmax_scale;
     int32_t device_id;
+    /* optional element mask of the forward, same convention as pfa_fa3_args.mask (u8, 0 = masked, BYTE strides, 0
+     * broadcasts a dimension; a [B,Sk] key mask is mask_stride_b = Sk, _h = 0, _q = 0, _k = 1).  Masked scores get no
+     * gradient; rows the forward found fully masked (lse = -inf) get dq = 0 and contribute nothing to dk, dv. */
+    const uint8_t* mask;
+    int64_t mask_stride_b, mask_stride_h, mask_stride_q, mask_stride_k;
 } pfa_fa3_bwd_args;
 
 size_t pfa_fa3_bwd_workspace_bytes(const pfa_fa3_bwd_args* a);

@@ -62,6 +62,13 @@ def tril(Sq, Sk):
     return torch.tril(torch.ones(Sq, Sk, dtype=torch.bool)).view(1, 1, Sq, Sk)
 
 
+ONLY = [a for a in sys.argv[1:] if not a.startswith("-")]      # optional: regenerate only fixtures whose name starts so
+
+
+def wanted(name):
+    return not ONLY or any(name.startswith(o) for o in ONLY)
+
+
 def save(name, meta, **arrays):
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **arrays)
@@ -69,6 +76,8 @@ def save(name, meta, **arrays):
 
 
 def full_case(name, B, H, Sq, Sk, D, seed, causal=False, kv_valid=None, note=""):
+    if not wanted(name):
+        return
     q, k, v = synth.qkv(B, H, Sq, Sk, D, seed, "bf16")
     mask = None
     if causal:
@@ -87,6 +96,8 @@ def full_case(name, B, H, Sq, Sk, D, seed, causal=False, kv_valid=None, note="")
 def sampled_case(name, B, H, S, D, seed, causal, heads, rows, note=""):
     """Large shapes: run the reference on single (b,h) problems (heads are independent,
     flash_attention_3.py:162/231 batch over them) and keep sampled rows + whole-head sums."""
+    if not wanted(name):
+        return
     q, k, v = synth.qkv(B, H, S, S, D, seed, "bf16")
     mask = tril(S, S) if causal else None
     outs, sums, asums = [], [], []
@@ -103,17 +114,22 @@ def sampled_case(name, B, H, S, D, seed, causal, heads, rows, note=""):
          head_sum=np.asarray(sums), head_abs_sum=np.asarray(asums))
 
 
-def grad_case(name, B, H, Sq, Sk, D, seed, causal, note=""):
+def grad_case(name, B, H, Sq, Sk, D, seed, causal, note="", kv_valid=None):
     """Gradients of the REAL reference's core by autograd (the only backward the reference has):
     loss = sum(out * dout) with a fixed dout, so dq/dk/dv are the vector-Jacobian products the HIP backward returns."""
+    if not wanted(name):
+        return
     q, k, v = synth.qkv(B, H, Sq, Sk, D, seed, "bf16")
     dout = torch.from_numpy(synth.normal_f32((B, Sq, H, D), seed + 5)).to(torch.bfloat16)
     m = RefFA3(H * D, H).eval()
     qf, kf, vf = (t.float().permute(0, 2, 1, 3).clone().requires_grad_(True) for t in (q, k, v))
     mask = tril(Sq, Sk).expand(B, 1, Sq, Sk) if causal else None
+    if kv_valid is not None:
+        kp = (torch.arange(Sk) < kv_valid).view(1, 1, 1, Sk).expand(B, 1, Sq, Sk)
+        mask = kp if mask is None else (mask & kp)
     o, _ = m._flash_attention_forward(qf, kf, vf, mask, False)
     (o * dout.float().permute(0, 2, 1, 3)).sum().backward()
-    meta = dict(kind="grad", B=B, H=H, Sq=Sq, Sk=Sk, D=D, seed=seed, causal=causal, kv_valid=None, dtype="bf16",
+    meta = dict(kind="grad", B=B, H=H, Sq=Sq, Sk=Sk, D=D, seed=seed, causal=causal, kv_valid=kv_valid, dtype="bf16",
                 layout="BSHD", in_checksum=input_checksum(q, k, v), dout_seed=seed + 5, note=note)
     save(name, meta, out=o.detach().permute(0, 2, 1, 3).contiguous().numpy(),
          dq=qf.grad.permute(0, 2, 1, 3).contiguous().numpy(), dk=kf.grad.permute(0, 2, 1, 3).contiguous().numpy(),
@@ -122,6 +138,8 @@ def grad_case(name, B, H, Sq, Sk, D, seed, causal, note=""):
 
 def module_case(name, B, S, E, H, seed):
     """G1b: whole-module plumbing (fused QKV chunk order, head split/merge, out_proj)."""
+    if not wanted(name):
+        return
     m = RefFA3(E, H).eval()
     sd = {
         "qkv_proj.weight": torch.from_numpy(synth.normal_f32((3 * E, E), seed + 10)) * E ** -0.5,
@@ -165,6 +183,8 @@ def main():
     grad_case("g8_grad_s128_d128", 2, 2, 128, 128, 128, 3001, False, note="dense branch, autograd")
     grad_case("g8_grad_s640_d64_causal", 1, 2, 640, 640, 64, 3002, True, note="tiled branch, causal, autograd")
     grad_case("g8_grad_cross_200x333_d128", 1, 2, 200, 333, 128, 3003, False, note="Sq != Sk")
+    grad_case("g8_grad_s320_d64_kvtail_causal", 1, 2, 320, 320, 64, 3004, True, note="keys >= 290 masked (4-D mask) + causal",
+              kv_valid=290)
     # G6: BASELINE-shaped problems, sampled
     rows_1k = sorted(set(list(range(0, 8)) + list(range(500, 520)) + list(range(1016, 1024))))
     sampled_case("g6_c2", 4, 12, 1024, 64, 2002, False, [(0, 0), (1, 5), (3, 11)], rows_1k,

@@ -57,6 +57,7 @@ class PfaFa3BwdArgs(C.Structure):
         + [(f"{t}_stride_{a}", C.c_int64) for t in ("q", "k", "v", "o", "do", "dq", "dk", "dv") for a in "bhs"]
         + [(n, C.c_int32) for n in ("B", "H", "Sq", "Sk", "D", "dtype", "dtype_grad", "causal")]
         + [("softmax_scale", C.c_float), ("device_id", C.c_int32)]
+        + [("mask", C.c_void_p)] + [(f"mask_stride_{a}", C.c_int64) for a in "bhqk"]
     )
 
 

@@ -132,22 +132,22 @@ class FlashAttention3(nn.Module):
                 "FlashAttention3 runs on MI355X only: move the module and its inputs to a GPU "
                 "(this package ships no CPU or eager implementation of the core)")
         needs_grad = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)
-        if needs_grad:
-            # differentiable path: HIP forward (with LSE) + HIP backward (pfa_fa3_bwd).  It covers what the backward
-            # kernels cover: bf16/fp16 operands, causal flag, no explicit mask, no weights.
-            if attention_mask is not None or need_weights or q.dtype == torch.float32:
-                raise NotImplementedError(
-                    "autograd through the HIP path supports bf16/fp16 modules with is_causal only "
-                    "(no attention_mask, no need_weights); use torch.no_grad() for the other forward modes")
-            if self.training and self.dropout > 0:
-                raise NotImplementedError("attention dropout in training mode is not implemented on the HIP path")
-            return ops.fa3_attention(q, k, v, causal=is_causal, softmax_scale=self.scaling), None
         if self.training and self.dropout > 0:
             raise NotImplementedError("attention dropout in training mode is not implemented on the HIP path")
-
         # 2-D [B,Sk] masks take the cheap key-mask path (:166-167); 3-D / 4-D masks the general one (:168,:235)
         key_mask = attention_mask if (attention_mask is not None and attention_mask.dim() == 2) else None
         mask = attention_mask if (attention_mask is not None and attention_mask.dim() != 2) else None
+        if needs_grad:
+            # differentiable path: HIP forward (with LSE) + HIP backward (pfa_fa3_bwd), masks included.  The returned
+            # weights would not be differentiable, so they are refused rather than silently detached.
+            if need_weights:
+                raise NotImplementedError(
+                    "need_weights under autograd is not supported on the HIP path (the weights would carry no "
+                    "gradient); call with torch.no_grad() to get them")
+            cd = self.compute_dtype if q.dtype == torch.float32 else q.dtype
+            out = ops.fa3_attention(q.to(cd), k.to(cd), v.to(cd), causal=is_causal, key_mask=key_mask, mask=mask,
+                                    softmax_scale=self.scaling, out_dtype=q.dtype)
+            return out, None
 
         kw = dict(causal=is_causal, key_mask=key_mask, mask=mask, softmax_scale=self.scaling,
                   return_weights=need_weights)

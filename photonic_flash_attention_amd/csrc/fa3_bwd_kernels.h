@@ -33,6 +33,8 @@ struct BwdParams {
     void* dk;
     void* dv;
     const int32_t* seqlens_k;
+    const uint8_t* mask;   // optional element mask (KMASK kernels), byte strides
+    int64_t m_sb, m_sh, m_sq, m_sk;
     int64_t q_sb, q_sh, q_ss, k_sb, k_sh, k_ss, v_sb, v_sh, v_ss;
     int64_t o_sb, o_sh, o_ss, do_sb, do_sh, do_ss;
     int64_t dq_sb, dq_sh, dq_ss, dk_sb, dk_sh, dk_ss, dv_sb, dv_sh, dv_ss;
@@ -173,7 +175,7 @@ struct TileRead {
 
 // ---------------------------------------------------------------------------------------------------------------
 // dQ: forward geometry.  LDS stage = [K image | V image], double buffered (64 KiB at D = 128).
-template <typename T, int D, bool CAUSAL, typename OT>
+template <typename T, int D, bool CAUSAL, bool KMASK, typename OT>
 __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
     using E = Elem<T>;
     using v8 = typename E::v8;
@@ -210,6 +212,7 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
         qf[ks] = *(const v8*)(qp + (int64_t)qrow * p.q_ss + 16 * ks + 8 * h);
         gf[ks] = *(const v8*)(gp + (int64_t)qrow * p.do_ss + 16 * ks + 8 * h);
     }
+    const uint8_t* mrow = KMASK ? p.mask + (int64_t)b * p.m_sb + (int64_t)hh * p.m_sh + (int64_t)qrow * p.m_sq : nullptr;
     const int64_t stat = ((int64_t)b * p.H + hh) * p.Sq + qrow;
     const float lse = p.lse[stat];
     const float delta = p.delta[stat];
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
         }
         __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
         // masks only where a tile crosses the diagonal or the key tail (wave-uniform, a real branch)
-        if ((key_base + BLOCK_N > kv_len) || (CAUSAL && key_base + BLOCK_N - 1 > wave_q0)) {
+        if (KMASK || (key_base + BLOCK_N > kv_len) || (CAUSAL && key_base + BLOCK_N - 1 > wave_q0)) {
             asm volatile("" ::: "memory");
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -272,6 +275,7 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
                     const int key = key_base + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
                     bool ok = key < kv_len;
                     if (CAUSAL) ok = ok && (key <= my_q);
+                    if (KMASK) ok = ok && (mrow[(int64_t)min(key, p.Sk - 1) * p.m_sk] != 0);
                     s[kb][e] = ok ? s[kb][e] : -INFINITY;
                 }
         }
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
 
 // ---------------------------------------------------------------------------------------------------------------
 // dK, dV: key-stationary.  Workgroup = 4 waves x 32 keys = 128 keys; LDS stage = [Q image | dO image] (64 rows).
-template <typename T, int D, bool CAUSAL, typename OT>
+template <typename T, int D, bool CAUSAL, bool KMASK, typename OT>
 __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p) {
     using E = Elem<T>;
     using v8 = typename E::v8;
@@ -405,6 +409,7 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
     };
 
     const int krow = min(my_key, p.Sk - 1);
+    const uint8_t* mcol = KMASK ? p.mask + (int64_t)b * p.m_sb + (int64_t)hh * p.m_sh + (int64_t)krow * p.m_sk : nullptr;
     v8 kf[KS], vf[KS];                       // K^T / V^T B-operand fragments: lane (key r, h) holds X[key][16ks+8h..+7]
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -463,6 +468,13 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
             const int t = my_key - q_base - 4 * h;
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[e] = (t <= (e & 3) + 8 * (e >> 2)) ? s[e] : -INFINITY;
+        }
+        if constexpr (KMASK) {                  // element mask: column my_key, rows of this half
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int qi = min(q_base + (e & 3) + 8 * (e >> 2) + 4 * h, p.Sq - 1);
+                s[e] = (mcol[(int64_t)qi * p.m_sq] != 0) ? s[e] : -INFINITY;
+            }
         }
         // dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]   (16 query rows per s2)
         static_for<2>([&](auto s2c) {

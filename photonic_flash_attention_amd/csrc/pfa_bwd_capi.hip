@@ -42,16 +42,16 @@ int check_bwd(const pfa_fa3_bwd_args* a) {
     return PFA_OK;
 }
 
+template <typename T, int D, bool C, bool K>
+void pick_ck(bool g32, const void*& dq, const void*& dkdv) {
+    dq = g32 ? (const void*)&pfa::fa3_bwd_dq_kernel<T, D, C, K, float> : (const void*)&pfa::fa3_bwd_dq_kernel<T, D, C, K, T>;
+    dkdv = g32 ? (const void*)&pfa::fa3_bwd_dkdv_kernel<T, D, C, K, float> : (const void*)&pfa::fa3_bwd_dkdv_kernel<T, D, C, K, T>;
+}
 template <typename T, int D>
-void pick_kernels(bool causal, bool g32, const void*& delta, const void*& dq, const void*& dkdv) {
+void pick_kernels(bool causal, bool kmask, bool g32, const void*& delta, const void*& dq, const void*& dkdv) {
     delta = (const void*)&pfa::fa3_bwd_delta_kernel<T, D>;
-    if (causal) {
-        dq = g32 ? (const void*)&pfa::fa3_bwd_dq_kernel<T, D, true, float> : (const void*)&pfa::fa3_bwd_dq_kernel<T, D, true, T>;
-        dkdv = g32 ? (const void*)&pfa::fa3_bwd_dkdv_kernel<T, D, true, float> : (const void*)&pfa::fa3_bwd_dkdv_kernel<T, D, true, T>;
-    } else {
-        dq = g32 ? (const void*)&pfa::fa3_bwd_dq_kernel<T, D, false, float> : (const void*)&pfa::fa3_bwd_dq_kernel<T, D, false, T>;
-        dkdv = g32 ? (const void*)&pfa::fa3_bwd_dkdv_kernel<T, D, false, float> : (const void*)&pfa::fa3_bwd_dkdv_kernel<T, D, false, T>;
-    }
+    if (causal) kmask ? pick_ck<T, D, true, true>(g32, dq, dkdv) : pick_ck<T, D, true, false>(g32, dq, dkdv);
+    else kmask ? pick_ck<T, D, false, true>(g32, dq, dkdv) : pick_ck<T, D, false, false>(g32, dq, dkdv);
 }
 
 }  // namespace
@@ -69,6 +69,7 @@ int pfa_fa3_bwd(const pfa_fa3_bwd_args* a, void* stream) {
     pfa::BwdParams p;
     p.q = a->q; p.k = a->k; p.v = a->v; p.o = a->o; p.dout = a->dout; p.lse = a->lse; p.delta = a->delta;
     p.dq = a->dq; p.dk = a->dk; p.dv = a->dv; p.seqlens_k = a->seqlens_k;
+    p.mask = a->mask; p.m_sb = a->mask_stride_b; p.m_sh = a->mask_stride_h; p.m_sq = a->mask_stride_q; p.m_sk = a->mask_stride_k;
     p.q_sb = a->q_stride_b; p.q_sh = a->q_stride_h; p.q_ss = a->q_stride_s;
     p.k_sb = a->k_stride_b; p.k_sh = a->k_stride_h; p.k_ss = a->k_stride_s;
     p.v_sb = a->v_stride_b; p.v_sh = a->v_stride_h; p.v_ss = a->v_stride_s;
@@ -82,13 +83,13 @@ int pfa_fa3_bwd(const pfa_fa3_bwd_args* a, void* stream) {
     p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
 
     const void *kdelta, *kdq, *kdkdv;
-    const bool causal = a->causal != 0, g32 = a->dtype_grad == PFA_DTYPE_FP32;
+    const bool causal = a->causal != 0, g32 = a->dtype_grad == PFA_DTYPE_FP32, kmask = a->mask != nullptr;
     if (a->dtype == PFA_DTYPE_BF16) {
-        if (a->D == 128) pick_kernels<__bf16, 128>(causal, g32, kdelta, kdq, kdkdv);
-        else pick_kernels<__bf16, 64>(causal, g32, kdelta, kdq, kdkdv);
+        if (a->D == 128) pick_kernels<__bf16, 128>(causal, kmask, g32, kdelta, kdq, kdkdv);
+        else pick_kernels<__bf16, 64>(causal, kmask, g32, kdelta, kdq, kdkdv);
     } else {
-        if (a->D == 128) pick_kernels<_Float16, 128>(causal, g32, kdelta, kdq, kdkdv);
-        else pick_kernels<_Float16, 64>(causal, g32, kdelta, kdq, kdkdv);
+        if (a->D == 128) pick_kernels<_Float16, 128>(causal, kmask, g32, kdelta, kdq, kdkdv);
+        else pick_kernels<_Float16, 64>(causal, kmask, g32, kdelta, kdq, kdkdv);
     }
     int prev = -1;
     hipError_t e = hipGetDevice(&prev);

@@ -182,11 +182,12 @@ def fa3_forward_bshd(q, k, v, **kw):
     return (res[0].permute(0, 2, 1, 3),) + tuple(res[1:])
 
 
-def fa3_backward(q, k, v, out, dout, lse, *, causal: bool = False, seqlens_k=None,
+def fa3_backward(q, k, v, out, dout, lse, *, causal: bool = False, seqlens_k=None, key_mask=None, mask=None,
                  softmax_scale: Optional[float] = None, grad_dtype: Optional[torch.dtype] = None):
     """dQ, dK, dV of ``fa3_forward`` (``pfa_fa3_bwd``).  All operands ``[B,H,S,D]``-shaped (any strides, head dim
     contiguous), ``lse`` the forward's ``[B,H,Sq]`` fp32 LSE.  Returns gradients as ``[B,H,S,D]`` views of
-    ``[B,S,H,D]`` buffers, in ``grad_dtype`` (input dtype by default, or fp32)."""
+    ``[B,S,H,D]`` buffers, in ``grad_dtype`` (input dtype by default, or fp32).  ``key_mask`` / ``mask``: the masks
+    the forward was called with (same conventions as ``fa3_forward``)."""
     B, H, Sq, D = q.shape
     Sk = k.shape[2]
     gdt = q.dtype if grad_dtype is None else grad_dtype
@@ -211,6 +212,18 @@ def fa3_backward(q, k, v, out, dout, lse, *, causal: bool = False, seqlens_k=Non
         sl = torch.as_tensor(seqlens_k, dtype=torch.int32, device=q.device).contiguous()
         a.seqlens_k = sl.data_ptr()
         keep.append(sl)
+    if key_mask is not None:
+        if mask is not None:
+            raise ValueError("pass either key_mask or mask")
+        if key_mask.shape != (B, Sk):
+            raise ValueError("key_mask must be [B, Sk]")
+        mask = key_mask
+    if mask is not None:
+        m4 = _as_mask4(mask, B, H, Sq, Sk, q.device)
+        a.mask = m4.data_ptr()
+        st = [0 if m4.shape[i] == 1 else m4.stride(i) for i in range(4)]
+        a.mask_stride_b, a.mask_stride_h, a.mask_stride_q, a.mask_stride_k = st[0], st[1], st[2], (st[3] or 1)
+        keep.append(m4)
     a.B, a.H, a.Sq, a.Sk, a.D = B, H, Sq, Sk, D
     a.dtype, a.dtype_grad, a.causal = _DT[q.dtype], _DT[gdt], 1 if causal else 0
     a.softmax_scale = float(D ** -0.5 if softmax_scale is None else softmax_scale)
@@ -226,23 +239,29 @@ def fa3_backward(q, k, v, out, dout, lse, *, causal: bool = False, seqlens_k=Non
 
 
 class _FA3Function(torch.autograd.Function):
-    """Differentiable ``fa3_forward`` (causal / seqlens_k masks): saves q, k, v, o and the LSE."""
+    """Differentiable ``fa3_forward`` (causal / seqlens_k / key / element masks): saves q, k, v, o and the LSE.
+    ``out_dtype`` fp32 (fp32 modules) runs the parity forward (fp32 store) and keeps a 16-bit copy of O for the
+    backward's delta = rowsum(dO o O)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, causal, seqlens_k, softmax_scale):
-        out, lse = fa3_forward(q, k, v, causal=causal, seqlens_k=seqlens_k, softmax_scale=softmax_scale, return_lse=True)
-        ctx.save_for_backward(q, k, v, out, lse)
+    def forward(ctx, q, k, v, causal, seqlens_k, softmax_scale, key_mask, mask, out_dtype):
+        out, lse = fa3_forward(q, k, v, causal=causal, seqlens_k=seqlens_k, key_mask=key_mask, mask=mask,
+                               softmax_scale=softmax_scale, return_lse=True, out_dtype=out_dtype)
+        o16 = out if out.dtype == q.dtype else out.to(q.dtype)
+        ctx.save_for_backward(q, k, v, o16, lse)
         ctx.causal, ctx.seqlens_k, ctx.softmax_scale = causal, seqlens_k, softmax_scale
+        ctx.key_mask, ctx.mask = key_mask, mask          # masks carry no gradient
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q, k, v, out, lse = ctx.saved_tensors
-        dq, dk, dv = fa3_backward(q, k, v, out, dout, lse, causal=ctx.causal, seqlens_k=ctx.seqlens_k,
-                                  softmax_scale=ctx.softmax_scale)
-        return dq, dk, dv, None, None, None
+        dq, dk, dv = fa3_backward(q, k, v, out, dout.to(q.dtype), lse, causal=ctx.causal, seqlens_k=ctx.seqlens_k,
+                                  key_mask=ctx.key_mask, mask=ctx.mask, softmax_scale=ctx.softmax_scale)
+        return dq, dk, dv, None, None, None, None, None, None
 
 
-def fa3_attention(q, k, v, *, causal: bool = False, seqlens_k=None, softmax_scale: Optional[float] = None):
-    """Autograd-aware attention on ``[B,H,S,D]`` operands: forward + backward on the HIP kernels."""
-    return _FA3Function.apply(q, k, v, causal, seqlens_k, softmax_scale)
+def fa3_attention(q, k, v, *, causal: bool = False, seqlens_k=None, key_mask=None, mask=None,
+                  softmax_scale: Optional[float] = None, out_dtype: Optional[torch.dtype] = None):
+    """Autograd-aware attention on ``[B,H,S,D]`` bf16/fp16 operands: forward + backward on the HIP kernels."""
+    return _FA3Function.apply(q, k, v, causal, seqlens_k, softmax_scale, key_mask, mask, out_dtype)

@@ -105,11 +105,113 @@ def test_backward_matches_reference_autograd_golden():
         q, k, v = golden_inputs(meta)
         dout = torch.from_numpy(synth.normal_f32((meta["B"], meta["Sq"], meta["H"], meta["D"]), meta["dout_seed"])).to(torch.bfloat16)
         qd, kd, vd, gd = (t.to(DEV).permute(0, 2, 1, 3) for t in (q, k, v, dout))
-        out, lse = ops.fa3_forward(qd, kd, vd, causal=meta["causal"], return_lse=True)
-        grads = ops.fa3_backward(qd, kd, vd, out, gd, lse, causal=meta["causal"], grad_dtype=torch.float32)
+        kw = {}
+        if meta.get("kv_valid") is not None:      # the reference was given a 4-D mask: feed the same one through `mask=`
+            Sq, Sk = meta["Sq"], meta["Sk"]
+            kw["mask"] = (torch.arange(Sk) < meta["kv_valid"]).view(1, 1, 1, Sk).expand(meta["B"], 1, Sq, Sk).to(DEV)
+        out, lse = ops.fa3_forward(qd, kd, vd, causal=meta["causal"], return_lse=True, **kw)
+        grads = ops.fa3_backward(qd, kd, vd, out, gd, lse, causal=meta["causal"], grad_dtype=torch.float32, **kw)
         for got, key in zip(grads, ("dq", "dk", "dv")):
             ref = torch.from_numpy(arr[key])
             got = got.permute(0, 2, 1, 3).cpu()
             err, scale = float((got - ref).abs().max()), float(ref.abs().max())
             print(f"{name} {key}: max-abs {err:.3e} (max |ref| {scale:.3e})")
             assert err <= 1.5e-2 * scale, (name, key, err, scale)
+
+
+# ---- masks in the backward ------------------------------------------------------------------------------------------
+def _torch_ref_masked(q, k, v, dout, keep, scale):
+    """fp64 torch reference on [B,S,H,D] operands with a boolean keep-mask broadcastable to [B,H,Sq,Sk]; rows with no
+    key kept give zero output and zero gradient (the kernel's documented convention for fully masked rows)."""
+    qf, kf, vf = (t.double().permute(0, 2, 1, 3).clone().requires_grad_(True) for t in (q, k, v))
+    s = (qf @ kf.transpose(-1, -2)) * scale
+    s = s.masked_fill(~keep, float("-inf"))
+    p = torch.nan_to_num(torch.softmax(s, dim=-1), nan=0.0)
+    out = p @ vf
+    out.backward(dout.double().permute(0, 2, 1, 3))
+    return [g.permute(0, 2, 1, 3).float() for g in (qf.grad, kf.grad, vf.grad)]
+
+
+MASK_CASES = [
+    # B, H, Sq, Sk, D, causal, kind
+    (2, 2, 128, 128, 64, False, "key"),
+    (1, 2, 200, 333, 128, False, "key"),
+    (2, 3, 192, 192, 128, False, "b1qk"),
+    (1, 2, 320, 320, 64, True, "bhqk"),
+    (1, 2, 256, 256, 128, False, "dead_rows"),
+]
+
+
+@pytest.mark.parametrize("case", MASK_CASES)
+def test_backward_with_masks(case):
+    from photonic_flash_attention_amd import ops
+    B, H, Sq, Sk, D, causal, kind = case
+    q, k, v = synth.qkv(B, H, Sq, Sk, D, 1300 + Sq, "bf16")
+    dout = torch.from_numpy(synth.normal_f32((B, Sq, H, D), 1400 + Sk)).to(q.dtype)
+    g = torch.Generator().manual_seed(Sq + Sk)
+    if kind == "key":
+        m = (torch.rand(B, Sk, generator=g) < 0.8)
+        m[:, 0] = True
+        keep = m[:, None, None, :]
+    elif kind == "b1qk":
+        m = (torch.rand(B, 1, Sq, Sk, generator=g) < 0.7)
+        m[..., 0] = True
+        keep = m
+    elif kind == "bhqk":
+        m = (torch.rand(B, H, Sq, Sk, generator=g) < 0.7)
+        m[..., 0] = True
+        keep = m
+    else:
+        m = (torch.rand(B, 1, Sq, Sk, generator=g) < 0.7)
+        m[..., 0] = True
+        m[:, :, 5] = False                    # fully masked rows
+        m[:, :, 100:133] = False
+        keep = m
+    full_keep = keep.expand(B, H, Sq, Sk).clone() if keep.shape[1] == H else keep.expand(B, 1, Sq, Sk).clone()
+    if causal:
+        full_keep = full_keep & torch.tril(torch.ones(Sq, Sk, dtype=torch.bool))
+    ref = _torch_ref_masked(q, k, v, dout, full_keep, D ** -0.5)
+    qd, kd, vd, gd = (t.to(DEV).permute(0, 2, 1, 3) for t in (q, k, v, dout))
+    kw = dict(key_mask=m.to(DEV)) if kind == "key" else dict(mask=m.to(DEV))
+    out, lse = ops.fa3_forward(qd, kd, vd, causal=causal, return_lse=True, **kw)
+    grads = ops.fa3_backward(qd, kd, vd, out, gd, lse, causal=causal, grad_dtype=torch.float32, **kw)
+    torch.cuda.synchronize()
+    for name, got, r in zip(("dq", "dk", "dv"), grads, ref):
+        got = got.permute(0, 2, 1, 3).cpu()
+        assert bool(torch.isfinite(got).all()), name
+        err, scale = float((got - r).abs().max()), float(r.abs().max())
+        assert err <= 1.5e-2 * scale + 1e-6, f"{name} {case}: err {err:.3e} vs max {scale:.3e}"
+    if kind == "dead_rows":
+        dq = grads[0].permute(0, 2, 1, 3).cpu()
+        assert float(dq[:, 5].abs().max()) == 0.0 and float(dq[:, 100:133].abs().max()) == 0.0
+
+
+def test_masked_module_trains_and_fp32_module_is_differentiable():
+    from photonic_flash_attention_amd import FlashAttention3
+    from oracle import fa3_oracle as orc
+    E, H, S = 128, 2, 96
+    m = FlashAttention3(E, H, dtype=torch.bfloat16).to(DEV).train()
+    x = torch.from_numpy(synth.normal_f32((2, S, E), 31)).to(DEV, torch.bfloat16).requires_grad_(True)
+    am = torch.ones(2, S)
+    am[0, 70:] = 0
+    am[1, 33:50] = 0
+    out, _ = m(x, attention_mask=am.to(DEV))
+    out.float().square().mean().backward()
+    sd = {k_: v_.detach().float().cpu().clone().requires_grad_(True) for k_, v_ in m.state_dict().items()}
+    xc = x.detach().float().cpu().requires_grad_(True)
+    ref = orc.module_forward(sd, H, xc, mask=am)
+    ref.square().mean().backward()
+    assert float((out.detach().float().cpu() - ref.detach()).abs().max()) <= 2e-2
+    gx = x.grad.float().cpu()
+    assert float((gx - xc.grad).abs().max()) <= 0.05 * float(xc.grad.abs().max()) + 1e-6
+    # fp32 module: the forward under autograd is the same parity forward as under no_grad
+    m32 = FlashAttention3(E, H).to(DEV).eval()
+    x32 = torch.from_numpy(synth.normal_f32((2, S, E), 32)).to(DEV).requires_grad_(True)
+    y = m32(x32, is_causal=True)[0]
+    with torch.no_grad():
+        y0 = m32(x32, is_causal=True)[0]
+    assert y.dtype == torch.float32 and torch.equal(y.detach(), y0)
+    y.square().mean().backward()
+    assert x32.grad is not None and bool(torch.isfinite(x32.grad).all()) and float(x32.grad.abs().sum()) > 0
+    for n_, p_ in m32.named_parameters():
+        assert p_.grad is not None and bool(torch.isfinite(p_.grad).all()), n_

@@ -178,7 +178,8 @@ def test_grad_mode_and_dropout_rules():
         m(x)
     m.eval()
     assert m(x)[0].requires_grad                        # eval + autograd: differentiable through pfa_fa3_bwd
-    with pytest.raises(NotImplementedError):           # ... but not with an explicit mask or weights
-        m(x, attention_mask=torch.ones(1, 16, device=DEV))
+    assert m(x, attention_mask=torch.ones(1, 16, device=DEV))[0].requires_grad    # ... masks included
+    with pytest.raises(NotImplementedError):           # ... but weights would carry no gradient: refused
+        m(x, need_weights=True)
     with torch.no_grad():
         assert m(x)[0].shape == x.shape                 # dropout is a no-op in eval (:174-175)

@@ -101,7 +101,8 @@ def test_oracle_autograd_matches_reference_autograd(name):
     q, k, v = golden_inputs(meta)
     dout = torch.from_numpy(synth.normal_f32((meta["B"], meta["Sq"], meta["H"], meta["D"]), meta["dout_seed"])).to(torch.bfloat16)
     qf, kf, vf = (t.float().clone().requires_grad_(True) for t in (q, k, v))
-    out = orc.attention_bshd(qf, kf, vf, causal=meta["causal"])
+    lens = None if meta.get("kv_valid") is None else [meta["kv_valid"]] * meta["B"]
+    out = orc.attention_bshd(qf, kf, vf, causal=meta["causal"], seqlens_k=lens)
     (out * dout.float()).sum().backward()
     assert float((out.detach() - torch.from_numpy(arr["out"])).abs().max()) <= ORACLE_TOL
     for g, key in ((qf.grad, "dq"), (kf.grad, "dk"), (vf.grad, "dv")):
