@@ -16,8 +16,9 @@
 //    file and are touched only by inline-asm MFMAs ("a" constraints), so hipcc never copies them through VGPRs.
 //    K runs one tile ahead of V in the LDS rings (2 slots each, 64 KiB); one barrier per 64-key tile.
 //    The O rescale decided in phase B (rare: defer-max) is applied after that phase's MFMAs.
-//  * tiles that need element masks (causal diagonal, key tail) and the last tile take the same steps without the
-//    interleave (`plain`), so the arithmetic is identical on both paths.
+//  * one loop body for every tile: masks (causal diagonal, key tail) are a wave-uniform branch between the two phases,
+//    and a wave's last iteration treats the non-existent next tile as fully masked (its softmax start then leaves
+//    m, l and O untouched) -- a second, non-interleaved body costs hipcc 300-600 bytes of scratch per lane.
 #pragma once
 #include "fa3_fwd_kernel.h"
 
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
     constexpr int TILE_BYTES = BLOCK_N * D * 2, HALF_TILE = TILE_BYTES / 2;
     constexpr int K_BASE = 0, V_BASE = 2 * TILE_BYTES;
     constexpr int PPW = (TILE_BYTES / 1024) / NW;          // 4 DMA pieces per wave per image
-    constexpr int PFK = 2, PFV = 2;                        // operand-fragment rings (steps ahead)
+    constexpr int PFK = 4, PFV = 3;                        // operand-fragment rings (steps ahead)
 
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const uint32_t smem_base = (uint32_t)(uintptr_t)(lds_char*)smem;
@@ -141,19 +142,29 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
         voffd = (uint32_t)(R0 * (int)p.v_ss + cc * 8) * 2u;
     }
     const uint32_t k_slab = (uint32_t)(((int64_t)(p.Sk - 1) * p.k_ss + D) * 2), v_slab = (uint32_t)(((int64_t)(p.Sk - 1) * p.v_ss + D) * 2);
-    auto srd_at = [](const char* base, uint32_t off, uint32_t slab) {
-        const uint64_t a = (uint64_t)(uintptr_t)(base + off);
+    // One descriptor per image for the whole kernel (base = the head's K / V slab, records = its bytes): the tile and
+    // piece offsets ride in the per-lane offset (one s_add + one v_add per piece), so the range check still zero-fills
+    // rows past Sk and nothing is rebuilt on the SALU per piece.  M0 is declared clobbered instead of saved/restored.
+    auto whole_srd = [](const char* base, uint32_t bytes) {
+        const uint64_t a = (uint64_t)(uintptr_t)base;
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
         return __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)(((uint64_t)hi << 32) | lo), 0,
-                                                 (int)__builtin_amdgcn_readfirstlane(slab > off ? slab - off : 0u), 0x00020000);
+                                                 (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
     };
-    auto dma_k = [&](int j, int t) {      // piece t of K(j); rows past Sk (and whole tiles past the last) arrive as zeros
-        const uint32_t off = ((uint32_t)j * (uint32_t)(BLOCK_N * 2) + (uint32_t)(32 * t)) * (uint32_t)p.k_ss;
-        lds_dma16_buf(srd_at(kp, j < nt ? off : k_slab, k_slab), koffd, smem_base + K_BASE + (j & 1) * TILE_BYTES + (wave + NW * t) * 1024);
+    const srd_t ksrd = whole_srd(kp, k_slab), vsrd = whole_srd(vp, v_slab);
+    auto dma_piece = [](srd_t srd, uint32_t voff, uint32_t lds_dst) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(srd), "s"(lds_dst)
+                     : "memory", "m0");
+    };
+    const uint32_t k_tile = (uint32_t)(BLOCK_N * 2) * (uint32_t)p.k_ss, v_tile = (uint32_t)(BLOCK_N * 2) * (uint32_t)p.v_ss;
+    const uint32_t k_step = 32u * (uint32_t)p.k_ss, v_step = 32u * (uint32_t)p.v_ss;
+    auto dma_k = [&](int j, int t) {      // piece t of K(j); rows past Sk arrive as zeros; tiles past the workgroup's last are fetched but never read
+        const uint32_t off = __builtin_amdgcn_readfirstlane(min((uint32_t)j * k_tile + (uint32_t)t * k_step, k_slab));
+        dma_piece(ksrd, koffd + off, smem_base + K_BASE + (j & 1) * TILE_BYTES + (wave + NW * t) * 1024);
     };
     auto dma_v = [&](int j, int t) {
-        const uint32_t off = ((uint32_t)j * (uint32_t)(BLOCK_N * 2) + (uint32_t)(32 * t)) * (uint32_t)p.v_ss;
-        lds_dma16_buf(srd_at(vp, j < nt ? off : v_slab, v_slab), voffd, smem_base + V_BASE + (j & 1) * TILE_BYTES + (wave + NW * t) * 1024);
+        const uint32_t off = __builtin_amdgcn_readfirstlane(min((uint32_t)j * v_tile + (uint32_t)t * v_step, v_slab));
+        dma_piece(vsrd, voffd + off, smem_base + V_BASE + (j & 1) * TILE_BYTES + (wave + NW * t) * 1024);
     };
 
     // ---- per-lane LDS read addresses (opaque: see VAR_DIET in fa3_fwd_kernel.h) ---------------------------------------------
@@ -173,42 +184,31 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
             asm volatile("" : "+v"(voff[db][hi]));
         }
 
-    // ---- the steps of one tile ---------------------------------------------------------------------------------------------
-    // A tile's work is cut into 16 QK^T steps, 16 softmax-finish pieces, 16 PV steps and 16 softmax-start pieces; the
-    // interleaved iteration pairs them one to one, the plain iteration runs them back to back.
+    // ---- the half-steps of one tile -----------------------------------------------------------------------------------------
+    // One half-step = ONE MFMA plus the vector work issued in its 32-cycle shadow (an in-order wave that issues two MFMAs
+    // back to back stalls on the second until the pipe is free and wastes the first one's shadow).  A tile is 32 QK^T
+    // half-steps (phase A, beside the softmax FINISH of the previous tile) and 32 PV half-steps (phase B, beside the
+    // softmax START of the next tile).  Half-step hs: fragment step hs / 2, query block hs % 2.
     v8 kfr[PFK];
     auto k_read = [&](int slot, int i) { return *(const lds_v8*)(uintptr_t)(koff[i % KS] + slot * TILE_BYTES + (i / KS) * HALF_TILE); };
     auto qk_begin = [&](int slot) {
 #pragma unroll
         for (int i = 0; i < PFK; ++i) kfr[i] = k_read(slot, i);
     };
-    // step i: key block kb = i / 8, k-step ks = i % 8; one K fragment, two MFMAs
-    auto qk_step = [&](auto ic, int slot, f32x16 (&sa)[2], f32x16 (&sb)[2]) {
-        constexpr int i = decltype(ic)::value, kb = i / KS, ks = i % KS;
-        if constexpr (ks == 0) {
-            M::s0(sa[kb], kfr[i % PFK], A.qf[ks]);
-            M::s0(sb[kb], kfr[i % PFK], Bq.qf[ks]);
+    auto qk_half = [&](auto hc, int slot, f32x16 (&sa)[2], f32x16 (&sb)[2]) {
+        constexpr int hs = decltype(hc)::value, i = hs / 2, kb = i / KS, ks = i % KS;
+        if constexpr (hs % 2 == 0) {
+            if constexpr (ks == 0) M::s0(sa[kb], kfr[i % PFK], A.qf[ks]);
+            else M::s(sa[kb], kfr[i % PFK], A.qf[ks]);
         } else {
-            M::s(sa[kb], kfr[i % PFK], A.qf[ks]);
-            M::s(sb[kb], kfr[i % PFK], Bq.qf[ks]);
+            if constexpr (ks == 0) M::s0(sb[kb], kfr[i % PFK], Bq.qf[ks]);
+            else M::s(sb[kb], kfr[i % PFK], Bq.qf[ks]);
+            if constexpr (i + PFK < 2 * KS) kfr[i % PFK] = k_read(slot, i + PFK);
         }
-        if constexpr (i + PFK < 2 * KS) kfr[i % PFK] = k_read(slot, i + PFK);
     };
-    // softmax-finish piece i: block (i < 8 ? a : b), element pair q = i % 8 of key block 1 gets its exponentials; the
-    // pair's key-block-0 P dword and the previous pair's key-block-1 sum + P dword are produced alongside
+    // softmax finish, half-step hs: block (hs < 16 ? a : b), element e = hs % 16 of key block 1 gets its exponential;
+    // even e: the key-block-0 P dword of the pair (e, e+1); odd e: sum + P dword of the previous key-block-1 pair
     float ps1 = 0.f;
-    auto sm2_one = [&](QB& X, int q, f32x16 (&s)[2], uint32_t (&pd)[16]) {
-        const int e0 = 2 * q, e1 = e0 + 1;
-        s[1][e0] = fast_exp2(__builtin_fmaf(s[1][e0], c, -X.mc));
-        s[1][e1] = fast_exp2(__builtin_fmaf(s[1][e1], c, -X.mc));
-        pd[(e0 >> 3) * 4 + ((e0 & 7) >> 1)] = M::pack2(s[0][e0], s[0][e1]);
-        if (q > 0) {
-            ps1 += s[1][e0 - 2];
-            asm volatile("" : "+v"(ps1));
-            ps1 += s[1][e0 - 1];
-            pd[(2 + ((e0 - 2) >> 3)) * 4 + (((e0 - 2) & 7) >> 1)] = M::pack2(s[1][e0 - 2], s[1][e0 - 1]);
-        }
-    };
     auto sm2_end = [&](QB& X, f32x16 (&s)[2], uint32_t (&pd)[16]) {
         ps1 += s[1][14];
         asm volatile("" : "+v"(ps1));
@@ -217,16 +217,27 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
         X.l += X.ps0 + ps1;
         ps1 = 0.f;
     };
-    auto sm2_piece = [&](auto ic, f32x16 (&ca)[2], f32x16 (&cb)[2], uint32_t (&pa)[16], uint32_t (&pb)[16]) {
-        constexpr int i = decltype(ic)::value;
-        if constexpr (i < 8) {
-            sm2_one(A, i, ca, pa);
-        } else {
-            if constexpr (i == 8) sm2_end(A, ca, pa);
-            sm2_one(Bq, i - 8, cb, pb);
+    auto sm2_one = [&](QB& X, int e, f32x16 (&s)[2], uint32_t (&pd)[16]) {
+        s[1][e] = fast_exp2(__builtin_fmaf(s[1][e], c, -X.mc));
+        if ((e & 1) == 0) {
+            pd[(e >> 3) * 4 + ((e & 7) >> 1)] = M::pack2(s[0][e], s[0][e + 1]);
+        } else if (e >= 3) {
+            ps1 += s[1][e - 3];
+            asm volatile("" : "+v"(ps1));
+            ps1 += s[1][e - 2];
+            pd[(2 + ((e - 3) >> 3)) * 4 + (((e - 3) & 7) >> 1)] = M::pack2(s[1][e - 3], s[1][e - 2]);
         }
     };
-    // PV step idx: k-step (kb, s2) = idx / 4, d block db = idx % 4; one V^T fragment (two transposed reads), two MFMAs
+    auto sm2_half = [&](auto hc, f32x16 (&ca)[2], f32x16 (&cb)[2], uint32_t (&pa)[16], uint32_t (&pb)[16]) {
+        constexpr int hs = decltype(hc)::value;
+        if constexpr (hs < 16) {
+            sm2_one(A, hs, ca, pa);
+        } else {
+            if constexpr (hs == 16) sm2_end(A, ca, pa);
+            sm2_one(Bq, hs - 16, cb, pb);
+        }
+    };
+    // PV half-step: fragment step idx = hs / 2 -> k-step (kb, s2) = idx / 4, d block db = idx % 4
     v4 vlo[PFV], vhi[PFV];
     auto v_read = [&](int slot, int idx, v4& lo, v4& hi4) {
         const uint32_t ko = slot * TILE_BYTES + (idx / 8) * HALF_TILE + ((idx / 4) & 1) * 16 * 256;
@@ -237,62 +248,74 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
 #pragma unroll
         for (int i = 0; i < PFV; ++i) v_read(slot, i, vlo[i], vhi[i]);
     };
-    auto pv_step = [&](auto ic, int slot, const uint32_t (&pa)[16], const uint32_t (&pb)[16]) {
-        constexpr int idx = decltype(ic)::value, f = idx / 4, db = idx % 4;
+    auto pv_half = [&](auto hc, int slot, const uint32_t (&pa)[16], const uint32_t (&pb)[16]) {
+        constexpr int hs = decltype(hc)::value, idx = hs / 2, f = idx / 4, db = idx % 4;
         v8 a;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             a[e] = vlo[idx % PFV][e];
             a[4 + e] = vhi[idx % PFV][e];
         }
-        const u32x4 fa = {pa[4 * f], pa[4 * f + 1], pa[4 * f + 2], pa[4 * f + 3]};
-        const u32x4 fb = {pb[4 * f], pb[4 * f + 1], pb[4 * f + 2], pb[4 * f + 3]};
-        M::o(A.o[db], a, fa);
-        M::o(Bq.o[db], a, fb);
-        if constexpr (idx + PFV < 16) v_read(slot, idx + PFV, vlo[idx % PFV], vhi[idx % PFV]);
+        if constexpr (hs % 2 == 0) {
+            const u32x4 fa = {pa[4 * f], pa[4 * f + 1], pa[4 * f + 2], pa[4 * f + 3]};
+            M::o(A.o[db], a, fa);
+        } else {
+            const u32x4 fb = {pb[4 * f], pb[4 * f + 1], pb[4 * f + 2], pb[4 * f + 3]};
+            M::o(Bq.o[db], a, fb);
+            if constexpr (idx + PFV < 16) v_read(slot, idx + PFV, vlo[idx % PFV], vhi[idx % PFV]);
+        }
     };
-    // softmax-start piece idx: block (idx < 8 ? a : b), local step t = idx % 8: t 0-1 row max and the (branch-free,
-    // per-row) defer-max update, t 2-7 the exponentials and sums of key block 0
+    // softmax start, half-step hs: block (hs < 16 ? a : b), local u = hs % 16: u 0-3 row max (8 values each, then the
+    // lane pair), u 4 the branch-free per-row defer-max update, u 5-15 the exponentials and sums of key block 0
     float mx_carry = 0.f;
-    auto sm1_one = [&](QB& X, int t, f32x16 (&s)[2]) {
-        if (t == 0) {
-            mx_carry = max16_first(s[0]);
-        } else if (t == 1) {
-            float mx = max16_next(mx_carry, s[1]);
-            mx = row_pair_max_asm(mx);
-            const bool grow = mx > X.m_thr;                  // this row's max outgrew the headroom
-            const float m_new = grow ? fmaxf(X.m, mx) : X.m;
-            const float al = grow ? fast_exp2((X.m - m_new) * c) : 1.0f;
+    auto sm1_one = [&](QB& X, int u, f32x16 (&s)[2]) {
+        if (u < 4) {
+            const f32x16& t = s[u >> 1];
+            const int o8 = (u & 1) * 8;
+            float mx = (u == 0) ? -INFINITY : mx_carry;
+            asm("v_max3_f32 %0, %0, %1, %2\n\tv_max3_f32 %0, %0, %3, %4\n\tv_max3_f32 %0, %0, %5, %6\n\tv_max3_f32 %0, %0, %7, %8"
+                : "+v"(mx)
+                : "v"(t[o8]), "v"(t[o8 + 1]), "v"(t[o8 + 2]), "v"(t[o8 + 3]), "v"(t[o8 + 4]), "v"(t[o8 + 5]), "v"(t[o8 + 6]), "v"(t[o8 + 7]));
+            mx_carry = (u == 3) ? row_pair_max_asm(mx) : mx;
+        } else if (u == 4) {
+            // branch-free, per row: a max inside the headroom leaves m alone, and then alpha = exp2(0) = 1 exactly
+            const float m_new = (mx_carry > X.m_thr) ? mx_carry : X.m;
+            const float al = fast_exp2((X.m - m_new) * c);
             X.m = m_new;
-            X.m_thr = grow ? m_new + thr : X.m_thr;
+            X.m_thr = m_new + thr;
             X.mc = m_new * c;
             X.l *= al;
             X.alpha = al;                                    // O *= alpha after the PV MFMAs in flight beside this
             X.ps0 = 0.f;
         } else {
-            const int lo = (t - 2) * 3, hi = (t == 7) ? 16 : lo + 3;
+            // 16 elements over 11 half-steps: 2,1,2,1,2,1,2,1,2,1,1  (running the v_fma one element ahead of its v_exp and the
+            // sum one behind was measured 3 % slower)
+            const int v = u - 5, lo = (v / 2) * 3 + (v & 1) * 2, n = (v == 10) ? 1 : ((v & 1) ? 1 : 2);
 #pragma unroll
-            for (int e = lo; e < hi; ++e) {
+            for (int e = lo; e < lo + n; ++e) {
                 s[0][e] = fast_exp2(__builtin_fmaf(s[0][e], c, -X.mc));
                 X.ps0 += s[0][e];
                 asm volatile("" : "+v"(X.ps0));
             }
         }
     };
-    auto sm1_piece = [&](auto ic, f32x16 (&na)[2], f32x16 (&nb)[2]) {
-        constexpr int idx = decltype(ic)::value;
-        if constexpr (idx < 8) sm1_one(A, idx, na);
-        else sm1_one(Bq, idx - 8, nb);
+    auto sm1_half = [&](auto hc, f32x16 (&na)[2], f32x16 (&nb)[2]) {
+        constexpr int hs = decltype(hc)::value;
+        if constexpr (hs < 16) sm1_one(A, hs, na);
+        else sm1_one(Bq, hs - 16, nb);
     };
-    auto apply_mask = [&](QB& X, f32x16 (&s)[2], int key_base) {
+    // element masks without control flow: key(kb, e) < lim  <=>  32 kb + (e & 3) + 8 (e >> 2) < lim - key_base - 4 h
+    auto apply_mask = [&](QB& X, f32x16 (&s)[2], int key_base, bool none = false) {
+        int lim = none ? 0 : kv_len;
+        if (CAUSAL) lim = min(lim, X.my_q + 1);
+        const int t = lim - key_base - 4 * h;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int key = key_base + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
-                bool ok = key < kv_len;
-                if (CAUSAL) ok = ok && (key <= X.my_q);
-                s[kb][e] = ok ? s[kb][e] : -INFINITY;
+                float x = s[kb][e];
+                x = (32 * kb + (e & 3) + 8 * (e >> 2) < t) ? x : -INFINITY;
+                s[kb][e] = x;
             }
     };
     auto needs_mask = [&](int key_base) { return (key_base + BLOCK_N > kv_len) || (CAUSAL && key_base + BLOCK_N - 1 > wave_q0); };
@@ -322,77 +345,70 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
 
     // ---- iterations ---------------------------------------------------------------------------------------------------------
     // interleaved: tile j's finish + PV beside tile j+1's QK^T + start (no masks on tile j+1)
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
     auto steady = [&](auto pc, int j, f32x16 (&ca)[2], f32x16 (&cb)[2], f32x16 (&na)[2], f32x16 (&nb)[2]) {
         constexpr int P = decltype(pc)::value;
         uint32_t pa[16], pb[16];
+#ifdef PFA_W4_STAMP
+        const unsigned long long t0 = stamp();
+#endif
         qk_begin(P ^ 1);
-        w4_for<16>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-            qk_step(ic, P ^ 1, na, nb);
-            if constexpr (i % 4 == 1) dma_v(j + 1, i / 4);
-            sm2_piece(ic, ca, cb, pa, pb);
+        w4_for<32>([&](auto hc) {
+            constexpr int hs = decltype(hc)::value;
+            qk_half(hc, P ^ 1, na, nb);
+            // the 8 DMA pieces early in phase A: they land under >= 1.5 phases of math before the barrier's vmcnt(0)
+            if constexpr (hs % 2 == 1 && hs < 8) dma_v(j + 1, hs / 2);
+            else if constexpr (hs % 2 == 1 && hs < 16) dma_k(j + 2, hs / 2 - 4);
+            sm2_half(hc, ca, cb, pa, pb);
             __builtin_amdgcn_sched_barrier(0);
         });
         sm2_end(Bq, cb, pb);
+#ifdef PFA_W4_STAMP
+        const unsigned long long t1 = stamp();
+        st_acc[0] += t1 - t0;
+#endif
+        // diagonal / key-tail tile, or no tile j+1 at all for this wave (then S(j+1) is junk and is masked out whole:
+        // its softmax start leaves m, l and O untouched): wave-uniform, rare
+        const bool last = j + 1 >= wnt;
+        if (last || needs_mask((j + 1) * BLOCK_N)) {
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // last QK^T MFMA -> VALU reads of S(j+1)
+            apply_mask(A, na, (j + 1) * BLOCK_N, last);
+            apply_mask(Bq, nb, (j + 1) * BLOCK_N, last);
+        }
         pv_begin(P);
         __builtin_amdgcn_sched_barrier(0);
-        w4_for<16>([&](auto ic) {
-            constexpr int idx = decltype(ic)::value;
-            pv_step(ic, P, pa, pb);
-            if constexpr (idx % 3 == 1 && idx < 12) dma_k(j + 2, idx / 3);
-            sm1_piece(ic, na, nb);
+        w4_for<32>([&](auto hc) {
+            pv_half(hc, P, pa, pb);
+            sm1_half(hc, na, nb);
             __builtin_amdgcn_sched_barrier(0);
         });
-        rescale(A);
-        rescale(Bq);
-    };
-    // plain: the same steps back to back; tile j+1 (if this wave has one) may need masks
-    auto plain = [&](auto pc, int j, bool has_next, f32x16 (&ca)[2], f32x16 (&cb)[2], f32x16 (&na)[2], f32x16 (&nb)[2]) {
-        constexpr int P = decltype(pc)::value;
-        uint32_t pa[16], pb[16];
-        if (j + 1 < nt) {
-#pragma unroll
-            for (int t = 0; t < PPW; ++t) dma_v(j + 1, t);
-        }
-        if (j + 2 < nt) {
-#pragma unroll
-            for (int t = 0; t < PPW; ++t) dma_k(j + 2, t);
-        }
-        if (has_next) {
-            qk_begin(P ^ 1);
-            w4_for<16>([&](auto ic) { qk_step(ic, P ^ 1, na, nb); });
-        }
-        w4_for<16>([&](auto ic) { sm2_piece(ic, ca, cb, pa, pb); });
-        sm2_end(Bq, cb, pb);
-        pv_begin(P);
-        w4_for<16>([&](auto ic) { pv_step(ic, P, pa, pb); });
-        if (has_next) {
-            if (needs_mask((j + 1) * BLOCK_N)) {
-                asm volatile("" ::: "memory");
-                apply_mask(A, na, (j + 1) * BLOCK_N);
-                apply_mask(Bq, nb, (j + 1) * BLOCK_N);
-            }
-            w4_for<16>([&](auto ic) { sm1_piece(ic, na, nb); });
+#ifdef PFA_W4_STAMP
+        const unsigned long long t2 = stamp();
+        st_acc[1] += t2 - t1;
+        st_acc[4] += 1;
+#endif
+        if (__builtin_amdgcn_ballot_w64(A.alpha != 1.0f || Bq.alpha != 1.0f) != 0) {      // rare (defer-max)
             rescale(A);
             rescale(Bq);
         }
+#ifdef PFA_W4_STAMP
+        st_last = stamp();
+        st_acc[3] += st_last - t2;
+#endif
     };
     auto iter = [&](auto pc, int j, f32x16 (&ca)[2], f32x16 (&cb)[2], f32x16 (&na)[2], f32x16 (&nb)[2]) {
         if (j < wnt) {
-            const bool has_next = j + 1 < wnt;
-            if (has_next && !needs_mask((j + 1) * BLOCK_N)) steady(pc, j, ca, cb, na, nb);
-            else plain(pc, j, has_next, ca, cb, na, nb);
+            steady(pc, j, ca, cb, na, nb);
         } else {                     // this wave is past its last tile: keep feeding the rings, keep the barriers
-            if (j + 1 < nt) {
 #pragma unroll
-                for (int t = 0; t < PPW; ++t) dma_v(j + 1, t);
-            }
-            if (j + 2 < nt) {
+            for (int t = 0; t < PPW; ++t) dma_v(j + 1, t);
 #pragma unroll
-                for (int t = 0; t < PPW; ++t) dma_k(j + 2, t);
-            }
+            for (int t = 0; t < PPW; ++t) dma_k(j + 2, t);
         }
         publish();
+#ifdef PFA_W4_STAMP
+        if (j < wnt) st_acc[2] += stamp() - st_last;
+#endif
     };
 
     // ---- prologue -----------------------------------------------------------------------------------------------------------
@@ -415,14 +431,14 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
     publish();
     if (wnt > 0) {
         qk_begin(0);
-        w4_for<16>([&](auto ic) { qk_step(ic, 0, S0a, S0b); });
+        w4_for<32>([&](auto hc) { qk_half(hc, 0, S0a, S0b); });
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");              // last MFMA -> first VALU read of S
         if (needs_mask(0)) {
             asm volatile("" ::: "memory");
             apply_mask(A, S0a, 0);
             apply_mask(Bq, S0b, 0);
         }
-        w4_for<16>([&](auto ic) { sm1_piece(ic, S0a, S0b); });
+        w4_for<32>([&](auto hc) { sm1_half(hc, S0a, S0b); });
         A.alpha = 1.0f;                          // O is still zero
         Bq.alpha = 1.0f;
     }
@@ -433,6 +449,13 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
         if (j + 1 < nt) iter(IC<1>{}, j + 1, S1a, S1b, S0a, S0b);
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                  // last MFMA -> epilogue reads of O
+#ifdef PFA_W4_STAMP
+    if (lane == 0 && p.dbg) {
+        unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[i] = st_acc[i];
+    }
+#endif
 
     // ---- epilogue: normalise, 16-byte stores (cdna guide T21) ----------------------------------------------------------------------
     auto store_qb = [&](QB& X) {

@@ -13,6 +13,8 @@
 #include "fa3_fwd_stagger_kernel.h"
 #include "fa3_weights_kernel.h"
 
+namespace pfa { const void* w4_kernel(int dtype, bool causal, bool out32); }   // pfa_w4.hip
+
 namespace {
 
 thread_local int g_last_hip_error = 0;
@@ -70,11 +72,24 @@ Variant exp_variant(bool causal) {
                   : mk<__bf16, 128, false, false, false, VAR, __bf16>("bf16", "o16");
 }
 
+// 4 waves x 64 rows (fa3_fwd_w4_kernel.h): D = 128, single P, no element mask
+Variant w4_variant(const pfa_fa3_args* a, bool causal, bool out32) {
+    Variant v;
+    v.fn = pfa::w4_kernel(a->dtype_in == PFA_DTYPE_BF16 ? 0 : 1, causal, out32);
+    snprintf(v.name, sizeof(v.name), "fa3_fwd_w4_%s_d128_%s_%s", a->dtype_in == PFA_DTYPE_BF16 ? "bf16" : "fp16",
+             causal ? "causal" : "full", out32 ? "o32" : "o16");
+    v.lds_bytes = 4 * pfa::BLOCK_N * 128 * 2;
+    v.nthreads = 256;
+    v.block_m = 256;
+    return v;
+}
+
 Variant pick(const pfa_fa3_args* a) {
     const bool causal = a->causal != 0, split = (a->flags & PFA_FLAG_SPLIT_P) != 0;
     const bool kmask = a->key_mask != nullptr || a->mask != nullptr;
     const bool out32 = a->dtype_out == PFA_DTYPE_FP32;
     const unsigned var = (a->flags >> 8) & 0xffu;   // 0 = production default
+    if (var == 43 && a->D == 128 && !split && !kmask) return w4_variant(a, causal, out32);
     if (var != 0 && a->dtype_in == PFA_DTYPE_BF16 && a->D == 128 && !split && !kmask && !out32) {
         switch (var) {
             case 1: return exp_variant<pfa::VAR_SCHED | pfa::VAR_GLDS | pfa::VAR_BUFDMA>(causal);          // exact lazy rescale (no defer-max)

@@ -2,7 +2,7 @@
 // the kernel wants the 512-register budget and is iterated on separately from the 8-wave kernels in pfa_capi.hip.
 #include <hip/hip_runtime.h>
 
-#include "fa3_fwd_w4_kernel.h"   // next to this file
+#include "fa3_fwd_w4_kernel.h"
 
 namespace pfa {
 

@@ -183,3 +183,22 @@ def test_grad_mode_and_dropout_rules():
         m(x, need_weights=True)
     with torch.no_grad():
         assert m(x)[0].shape == x.shape                 # dropout is a no-op in eval (:174-175)
+
+
+def test_forward_is_capturable_in_a_hip_graph():
+    """Launch-bound shapes (BASELINE config C1) replay from a captured graph: the C ABI launches on the caller's
+    stream with no hidden synchronisation or allocation, so stream capture sees one kernel node per call."""
+    from photonic_flash_attention_amd import ops
+    q, k, v = (t.to(DEV).permute(0, 2, 1, 3) for t in synth.qkv(2, 4, 128, 128, 64, 1001, "bf16"))
+    out = torch.empty(2, 128, 4, 64, device=DEV, dtype=torch.bfloat16).permute(0, 2, 1, 3)
+    eager = ops.fa3_forward(q, k, v, causal=True)[0].clone()
+    g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ops.fa3_forward(q, k, v, causal=True, out=out)         # warm-up outside the capture (library load, attributes)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            ops.fa3_forward(q, k, v, causal=True, out=out)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)

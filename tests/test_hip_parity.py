@@ -228,3 +228,40 @@ def test_runs_to_run_determinism_and_variant_equivalence():
     for var in (2, 3, 4, 6, 9, 10, 11, 12, 18, 35):
         o, _ = ops.fa3_forward_bshd(q, k, v, causal=True, _variant=var)
         assert torch.equal(o, base), f"variant {var}"
+
+
+# ---- development variant 43: 4 waves x 64 rows, one wave per SIMD (csrc/fa3_fwd_w4_kernel.h) ----------------------------
+W4_CASES = [
+    # B, H, Sq, Sk, D, causal, seqlens
+    (1, 2, 256, 256, 128, False, None),
+    (2, 2, 512, 512, 128, True, None),
+    (1, 3, 200, 333, 128, False, None),       # ragged, Sq != Sk
+    (1, 2, 1000, 1000, 128, True, None),      # ragged causal
+    (2, 2, 300, 300, 128, False, [300, 41]),  # key lengths, one shorter than a tile
+    (1, 2, 640, 64, 128, False, None),        # a single key tile
+    (1, 4, 2048, 2048, 128, True, None),
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", W4_CASES)
+def test_w4_variant_matches_production_and_oracle(case, dtype):
+    """Same math, different schedule: the 4-wave kernel must agree with the production kernel to rounding noise and
+    with the oracle within the single-P (16-bit P) tolerance of 1e-2 max-abs."""
+    from photonic_flash_attention_amd import ops
+    from oracle import fa3_oracle as orc
+    from photonic_flash_attention_amd import _capi, synth
+    B, H, Sq, Sk, D, causal, lens = case
+    q, k, v = synth.qkv(B, H, Sq, Sk, D, 4300 + Sq, dtype)
+    qd, kd, vd = (t.to("cuda:0").permute(0, 2, 1, 3) for t in (q, k, v))
+    kw = dict(causal=causal, seqlens_k=lens, out_dtype=torch.float32, split_p=False, return_lse=True)
+    o0, l0 = ops.fa3_forward(qd, kd, vd, **kw)
+    o1, l1 = ops.fa3_forward(qd, kd, vd, _variant=43, **kw)
+    torch.cuda.synchronize()
+    args, _keep = ops.build_args(qd, kd, vd, o1, causal=causal, seqlens_k=lens, split_p=False, variant=43)
+    assert "w4" in _capi.describe(args)[0]
+    assert float((o0 - o1).abs().max()) <= 2e-5 and float((l0 - l1).abs().max()) <= 2e-5
+    ref = orc.attention_bshd(q, k, v, causal=causal, seqlens_k=lens)
+    assert float((o1.permute(0, 2, 1, 3).cpu() - ref).abs().max()) <= 1e-2
+    o16 = ops.fa3_forward(qd, kd, vd, causal=causal, seqlens_k=lens, _variant=43)[0]
+    assert float((o16.float() - o1).abs().max()) <= (2e-2 if dtype == "bf16" else 3e-3)      # 16-bit store rounding only
