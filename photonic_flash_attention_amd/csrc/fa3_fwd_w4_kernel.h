@@ -210,21 +210,27 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
     // even e: the key-block-0 P dword of the pair (e, e+1); odd e: sum + P dword of the previous key-block-1 pair
     float ps1 = 0.f;
     auto sm2_end = [&](QB& X, f32x16 (&s)[2], uint32_t (&pd)[16]) {
-        ps1 += s[1][14];
-        asm volatile("" : "+v"(ps1));
-        ps1 += s[1][15];
+#pragma unroll
+        for (int e = 12; e < 16; ++e) {
+            ps1 += s[1][e];
+            asm volatile("" : "+v"(ps1));
+        }
         pd[15] = M::pack2(s[1][14], s[1][15]);
         X.l += X.ps0 + ps1;
         ps1 = 0.f;
     };
+    // even e (half-steps with no LDS read to issue): exp(e), the key-block-0 P dword of (e, e+1), the sums of the
+    // key-block-1 pair finished two half-steps ago; odd e: exp(e) and the P dword of the previous key-block-1 pair
     auto sm2_one = [&](QB& X, int e, f32x16 (&s)[2], uint32_t (&pd)[16]) {
         s[1][e] = fast_exp2(__builtin_fmaf(s[1][e], c, -X.mc));
         if ((e & 1) == 0) {
             pd[(e >> 3) * 4 + ((e & 7) >> 1)] = M::pack2(s[0][e], s[0][e + 1]);
+            if (e >= 4) {
+                ps1 += s[1][e - 4];
+                asm volatile("" : "+v"(ps1));
+                ps1 += s[1][e - 3];
+            }
         } else if (e >= 3) {
-            ps1 += s[1][e - 3];
-            asm volatile("" : "+v"(ps1));
-            ps1 += s[1][e - 2];
             pd[(2 + ((e - 3) >> 3)) * 4 + (((e - 3) & 7) >> 1)] = M::pack2(s[1][e - 3], s[1][e - 2]);
         }
     };
@@ -288,9 +294,10 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
             X.alpha = al;                                    // O *= alpha after the PV MFMAs in flight beside this
             X.ps0 = 0.f;
         } else {
-            // 16 elements over 11 half-steps: 2,1,2,1,2,1,2,1,2,1,1  (running the v_fma one element ahead of its v_exp and the
-            // sum one behind was measured 3 % slower)
-            const int v = u - 5, lo = (v / 2) * 3 + (v & 1) * 2, n = (v == 10) ? 1 : ((v & 1) ? 1 : 2);
+            // 16 elements over 11 half-steps: 1,2,1,2,...,1 -- one on the odd half-steps (they also issue the two V^T
+            // reads and their wait), two on the even ones.  (Running the v_fma one element ahead of its v_exp and the
+            // sum one behind was measured 3 % slower.)
+            const int v = u - 5, lo = (v / 2) * 3 + (v & 1), n = (v & 1) ? 2 : 1;
 #pragma unroll
             for (int e = lo; e < lo + n; ++e) {
                 s[0][e] = fast_exp2(__builtin_fmaf(s[0][e], c, -X.mc));
@@ -356,9 +363,10 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
         w4_for<32>([&](auto hc) {
             constexpr int hs = decltype(hc)::value;
             qk_half(hc, P ^ 1, na, nb);
-            // the 8 DMA pieces early in phase A: they land under >= 1.5 phases of math before the barrier's vmcnt(0)
-            if constexpr (hs % 2 == 1 && hs < 8) dma_v(j + 1, hs / 2);
-            else if constexpr (hs % 2 == 1 && hs < 16) dma_k(j + 2, hs / 2 - 4);
+            __builtin_amdgcn_sched_barrier(0);      // the MFMA first, its shadow's work after it (hipcc otherwise alternates)
+            // 8 DMA pieces, one every fourth half-step: the last lands a full phase before the barrier's vmcnt(0)
+            if constexpr (hs % 4 == 1 && hs < 16) dma_v(j + 1, hs / 4);
+            else if constexpr (hs % 4 == 1) dma_k(j + 2, hs / 4 - 4);
             sm2_half(hc, ca, cb, pa, pb);
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -379,6 +387,7 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
         __builtin_amdgcn_sched_barrier(0);
         w4_for<32>([&](auto hc) {
             pv_half(hc, P, pa, pb);
+            __builtin_amdgcn_sched_barrier(0);
             sm1_half(hc, na, nb);
             __builtin_amdgcn_sched_barrier(0);
         });
