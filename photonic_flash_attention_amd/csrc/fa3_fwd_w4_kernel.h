@@ -35,9 +35,11 @@ template <> struct W4Asm<__bf16> {
     template <typename V8> static __device__ __forceinline__ void o(f32x16& o, V8 v, u32x4 p) {
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o) : "v"(v), "v"(p));
     }
-    static __device__ __forceinline__ uint32_t pack2(float a, float b) {
-        uint32_t r;
-        asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    static __device__ __forceinline__ uint32_t pack2(float a, float b) {      // one v_cvt_pk_bf16_f32 (plain C++: an asm
+        typedef __attribute__((ext_vector_type(2))) __bf16 b2;                 // statement costs an s_nop behind it)
+        const b2 t = {(__bf16)a, (__bf16)b};
+        const uint32_t r = __builtin_bit_cast(uint32_t, t);
+        asm volatile("" ::"v"(r));                                             // ... converted HERE, not sunk to its use
         return r;
     }
 };
@@ -54,7 +56,9 @@ template <> struct W4Asm<_Float16> {
     static __device__ __forceinline__ uint32_t pack2(float a, float b) {
         typedef __attribute__((ext_vector_type(2))) _Float16 h2;
         const h2 t = {(_Float16)a, (_Float16)b};
-        return __builtin_bit_cast(uint32_t, t);
+        const uint32_t r = __builtin_bit_cast(uint32_t, t);
+        asm volatile("" ::"v"(r));
+        return r;
     }
 };
 
@@ -213,7 +217,6 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
 #pragma unroll
         for (int e = 12; e < 16; ++e) {
             ps1 += s[1][e];
-            asm volatile("" : "+v"(ps1));
         }
         pd[15] = M::pack2(s[1][14], s[1][15]);
         X.l += X.ps0 + ps1;
@@ -223,12 +226,13 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
     // key-block-1 pair finished two half-steps ago; odd e: exp(e) and the P dword of the previous key-block-1 pair
     auto sm2_one = [&](QB& X, int e, f32x16 (&s)[2], uint32_t (&pd)[16]) {
         s[1][e] = fast_exp2(__builtin_fmaf(s[1][e], c, -X.mc));
+        if (e == 0) X.ps0 += s[0][15];            // left over from the softmax start (its sums lag by one half-step)
         if ((e & 1) == 0) {
             pd[(e >> 3) * 4 + ((e & 7) >> 1)] = M::pack2(s[0][e], s[0][e + 1]);
             if (e >= 4) {
                 ps1 += s[1][e - 4];
-                asm volatile("" : "+v"(ps1));
                 ps1 += s[1][e - 3];
+                asm volatile("" ::"v"(ps1));      // summed HERE (input-only anchor: no hazard nop behind it)
             }
         } else if (e >= 3) {
             pd[(2 + ((e - 3) >> 3)) * 4 + (((e - 3) & 7) >> 1)] = M::pack2(s[1][e - 3], s[1][e - 2]);
@@ -297,13 +301,14 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
             // 16 elements over 11 half-steps: 1,2,1,2,...,1 -- one on the odd half-steps (they also issue the two V^T
             // reads and their wait), two on the even ones.  (Running the v_fma one element ahead of its v_exp and the
             // sum one behind was measured 3 % slower.)
-            const int v = u - 5, lo = (v / 2) * 3 + (v & 1), n = (v & 1) ? 2 : 1;
+            const int v = u - 5, lo = (v / 2) * 3 + (v & 1), n = (v & 1) ? 2 : 1, nprev = (v == 0) ? 0 : ((v & 1) ? 1 : 2);
 #pragma unroll
-            for (int e = lo; e < lo + n; ++e) {
-                s[0][e] = fast_exp2(__builtin_fmaf(s[0][e], c, -X.mc));
-                X.ps0 += s[0][e];
-                asm volatile("" : "+v"(X.ps0));
-            }
+            for (int e = lo; e < lo + n; ++e) s[0][e] = fast_exp2(__builtin_fmaf(s[0][e], c, -X.mc));
+            // sums lag one half-step behind the exponentials (a VALU right behind the v_exp it depends on costs an
+            // s_nop); element 15 is added by the first finish half-step of the next iteration
+#pragma unroll
+            for (int e = lo - nprev; e < lo; ++e) X.ps0 += s[0][e];
+            asm volatile("" ::"v"(X.ps0));
         }
     };
     auto sm1_half = [&](auto hc, f32x16 (&na)[2], f32x16 (&nb)[2]) {
