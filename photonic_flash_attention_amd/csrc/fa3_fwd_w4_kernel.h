@@ -278,6 +278,7 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
     // softmax start, half-step hs: block (hs < 16 ? a : b), local u = hs % 16: u 0-3 row max (8 values each, then the
     // lane pair), u 4 the branch-free per-row defer-max update, u 5-15 the exponentials and sums of key block 0
     float mx_carry = 0.f;
+    uint64_t any_grow = 0;
     auto sm1_one = [&](QB& X, int u, f32x16 (&s)[2]) {
         if (u < 4) {
             const f32x16& t = s[u >> 1];
@@ -289,7 +290,9 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
             mx_carry = (u == 3) ? row_pair_max_asm(mx) : mx;
         } else if (u == 4) {
             // branch-free, per row: a max inside the headroom leaves m alone, and then alpha = exp2(0) = 1 exactly
-            const float m_new = (mx_carry > X.m_thr) ? mx_carry : X.m;
+            const bool grow = mx_carry > X.m_thr;
+            any_grow |= __builtin_amdgcn_ballot_w64(grow);   // scalar: decides the (rare) O rescale after this phase
+            const float m_new = grow ? mx_carry : X.m;
             const float al = fast_exp2((X.m - m_new) * c);
             X.m = m_new;
             X.m_thr = m_new + thr;
@@ -333,20 +336,18 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
     auto needs_mask = [&](int key_base) { return (key_base + BLOCK_N > kv_len) || (CAUSAL && key_base + BLOCK_N - 1 > wave_q0); };
     // the deferred O rescale (rare): O never leaves the accumulator file
     auto rescale = [&](QB& X) {
-        if (__builtin_amdgcn_ballot_w64(X.alpha != 1.0f) != 0) {
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // last MFMA -> v_accvgpr_read
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // last MFMA -> v_accvgpr_read
 #pragma unroll
-            for (int i = 0; i < DB; ++i)
+        for (int i = 0; i < DB; ++i)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float x = X.o[i][e], t;
-                    asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\ts_nop 1\n\tv_accvgpr_write_b32 %0, %1"
-                                 : "+a"(x), "=&v"(t)
-                                 : "v"(X.alpha));
-                    X.o[i][e] = x;
-                }
-            asm volatile("s_nop 7" ::: "memory");
-        }
+            for (int e = 0; e < 16; ++e) {
+                float x = X.o[i][e], t;
+                asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\ts_nop 1\n\tv_accvgpr_write_b32 %0, %1"
+                             : "+a"(x), "=&v"(t)
+                             : "v"(X.alpha));
+                X.o[i][e] = x;
+            }
+        asm volatile("s_nop 7" ::: "memory");
         X.alpha = 1.0f;
     };
     auto publish = [&]() {          // this wave's DMA pieces have landed; everyone is done with the slots about to be refilled
@@ -401,9 +402,10 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
         st_acc[1] += t2 - t1;
         st_acc[4] += 1;
 #endif
-        if (__builtin_amdgcn_ballot_w64(A.alpha != 1.0f || Bq.alpha != 1.0f) != 0) {      // rare (defer-max)
+        if (any_grow != 0) {                      // rare (defer-max): some row's max outgrew its headroom
             rescale(A);
             rescale(Bq);
+            any_grow = 0;
         }
 #ifdef PFA_W4_STAMP
         st_last = stamp();
@@ -455,6 +457,7 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
         w4_for<32>([&](auto hc) { sm1_half(hc, S0a, S0b); });
         A.alpha = 1.0f;                          // O is still zero
         Bq.alpha = 1.0f;
+        any_grow = 0;
     }
     __builtin_amdgcn_s_barrier();               // K slot 0 is free for K(2)
 
