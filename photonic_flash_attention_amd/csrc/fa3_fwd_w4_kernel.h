@@ -429,22 +429,21 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
 
     // ---- prologue -----------------------------------------------------------------------------------------------------------
     f32x16 S0a[2], S0b[2], S1a[2], S1b[2];      // S(j) of even / odd tiles
-    if (nt > 0) {
+    // The fill of a workgroup is bandwidth bound (Q 64 KiB + three 16-KiB tiles at ~11 B/cycle/CU): wait only for what the
+    // first QK^T needs (Q, K0) and let V0 and K1 land under QK^T(0) and the first softmax start.
 #pragma unroll
-        for (int t = 0; t < PPW; ++t) dma_k(0, t);
-#pragma unroll
-        for (int t = 0; t < PPW; ++t) dma_v(0, t);
-        if (nt > 1) {
-#pragma unroll
-            for (int t = 0; t < PPW; ++t) dma_k(1, t);
-        }
-    }
+    for (int t = 0; t < PPW; ++t) dma_k(0, t);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // Q rows (issued in init_qb) and this wave's K0 pieces
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {           // Q into the accumulator file, once
         asm volatile("" : "+a"(A.qf[ks]));
         asm volatile("" : "+a"(Bq.qf[ks]));
     }
-    publish();
+#pragma unroll
+    for (int t = 0; t < PPW; ++t) dma_v(0, t);
+#pragma unroll
+    for (int t = 0; t < PPW; ++t) dma_k(1, t);
+    __builtin_amdgcn_s_barrier();               // everyone's K0 pieces are in LDS
     if (wnt > 0) {
         qk_begin(0);
         w4_for<32>([&](auto hc) { qk_half(hc, 0, S0a, S0b); });
@@ -459,7 +458,7 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
         Bq.alpha = 1.0f;
         any_grow = 0;
     }
-    __builtin_amdgcn_s_barrier();               // K slot 0 is free for K(2)
+    publish();                                  // V0 and K1 landed; K slot 0 is free for K(2)
 
     for (int j = 0; j < nt; j += 2) {
         iter(IC<0>{}, j, S0a, S0b, S1a, S1b);

@@ -21,3 +21,5 @@ tiles = d[..., 4].sum()
 for i, n in enumerate(["phase A (QK + finish softmax + DMA issue)", "phase B (PV + start softmax)", "vmcnt + barrier", "rescale check"]):
     print(f"  {n:45s} {d[..., i].sum() / tiles:8.0f} cyc/tile")
 print(f"  total {d[..., :4].sum() / tiles:.0f} cycles per wave-tile over {int(tiles)} wave-tiles")
+w = d[..., 5:8].mean(dim=(0, 1))
+print(f"  per workgroup-wave: prologue {w[0]:.0f}, loop {w[1]:.0f}, epilogue (to last store done) {w[2]:.0f} cycles")
