@@ -261,3 +261,18 @@ def test_convert_to_photonic_replaces_torch_mha(monkeypatch):
     assert rep2.skipped_layers == ["0"] and "head_dim" in rep2.compatibility_warnings[0]
     with pytest.raises(ValueError):
         convert_to_photonic("bert-base-uncased")
+
+
+def test_integration_md_binding_matches_the_abi():
+    """The ctypes struct INTEGRATION.md tells a maintainer to paste must be the library's struct (same fields, same size)."""
+    import ctypes as C
+    import os
+    from photonic_flash_attention_amd import _capi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = src[src.index("class PfaFa3Args(C.Structure):"):src.index("_lib = C.CDLL")]
+    ns = {}
+    exec("import ctypes as C\n" + code, ns)
+    doc = ns["PfaFa3Args"]
+    assert [f[0] for f in doc._fields_] == [f[0] for f in _capi.PfaFa3Args._fields_]
+    assert C.sizeof(doc) == C.sizeof(_capi.PfaFa3Args)
