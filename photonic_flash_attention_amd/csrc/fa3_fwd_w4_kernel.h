@@ -477,11 +477,16 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
 #endif
 
     // ---- epilogue: normalise, 16-byte stores (cdna guide T21) ----------------------------------------------------------------------
-    auto store_qb = [&](QB& X) {
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+    auto store_qb = [&](QB& X, int blk) {
         const float l_tot = row_pair_sum(X.l);
         const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
         if constexpr (sizeof(OT) == 2) {
-            char* orow = (char*)((OT*)p.o + (int64_t)b * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)min(X.my_q, p.Sq - 1) * p.o_ss) + 16 * h;
+            // 16-bit store through LDS (free after the loop's last barrier; every wave uses its own 16 KiB): a lane pair
+            // first forms 16-byte chunks of its row (cdna guide T21), the block is written as a [32 rows][256 B] image
+            // with the chunk index XOR-swizzled by the row, and read back so that one store instruction covers four WHOLE
+            // rows -- per-lane stores at the row stride touch 64 cache lines per instruction, these touch 8.
+            const uint32_t lbase = smem_base + wave * 16384 + blk * 8192;
 #pragma unroll
             for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -496,8 +501,17 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
                     auto r0 = __builtin_amdgcn_permlane32_swap(ua[0], ub[0], false, false);
                     auto r1 = __builtin_amdgcn_permlane32_swap(ua[1], ub[1], false, false);
                     const u32x4 w = {r0[0], r1[0], r0[1], r1[1]};
-                    if (X.my_q < p.Sq) *(u32x4*)(orow + 2 * (db * 32 + 8 * g)) = w;
+                    const uint32_t ch = 4 * db + g + h;                   // 16-byte chunk of the row this lane now holds
+                    *(lds_u32x4*)(uintptr_t)(lbase + r * 256 + ((ch ^ (r & 15)) << 4)) = w;
                 }
+            const int first = X.my_q - r, cc = lane & 15;
+            char* obase = (char*)((OT*)p.o + (int64_t)b * p.o_sb + (int64_t)hh * p.o_sh) + 16 * cc;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = 4 * i + (lane >> 4);
+                const u32x4 x = *(const lds_u32x4*)(uintptr_t)(lbase + row * 256 + ((cc ^ (row & 15)) << 4));
+                if (first + row < p.Sq) *(u32x4*)(obase + (int64_t)(first + row) * p.o_ss * 2) = x;
+            }
         } else if (X.my_q < p.Sq) {
             OT* orow = (OT*)p.o + (int64_t)b * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)X.my_q * p.o_ss;
 #pragma unroll
@@ -515,8 +529,8 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
             p.lse[((int64_t)b * p.H + hh) * p.Sq + X.my_q] = lse;
         }
     };
-    store_qb(A);
-    store_qb(Bq);
+    store_qb(A, 0);
+    store_qb(Bq, 1);
 }
 
 }  // namespace pfa
