@@ -813,7 +813,12 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
         // 16-bit store: lanes l and l+32 hold the two 8-byte halves of every 16-byte column group of one row.  One
         // v_permlane32_swap per dword pairs group k (even) with k+1 so that each lane owns 16 contiguous bytes:
         // 8 dwordx4 stores per lane instead of 16 dwordx2 -- the tail is store-issue bound (cdna guide T21).
-        char* orow = (char*)((OT*)p.o + (int64_t)b * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)min(my_q, p.Sq - 1) * p.o_ss) + 16 * h;
+        // The 16-byte chunks then go through LDS (free after the loop's last barrier; 32 rows x D*2 bytes per wave, chunk
+        // index XOR-swizzled by the row) and come back so that one store instruction covers WHOLE rows: per-lane stores
+        // at the row stride touch 64 cache lines per instruction, these 8 (D = 128) or 16 (D = 64).
+        typedef __attribute__((address_space(3))) u32x4 lds_u32x4_t;
+        constexpr int RB = D * 2, CPRW = RB / 16, RPI = 64 / CPRW;      // row bytes, chunks per row, rows per store instruction
+        const uint32_t lbase = smem_base + wave * (32 * RB);
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
@@ -828,8 +833,17 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
                 auto r0 = __builtin_amdgcn_permlane32_swap(a[0], bq[0], false, false);
                 auto r1 = __builtin_amdgcn_permlane32_swap(a[1], bq[1], false, false);
                 u32x4 w = {r0[0], r1[0], r0[1], r1[1]};
-                if (my_q < p.Sq) *(u32x4*)(orow + 2 * (db * 32 + 8 * g)) = w;
+                const uint32_t ch = 4 * db + g + h;
+                *(lds_u32x4_t*)(uintptr_t)(lbase + r * RB + ((ch ^ (r & (CPRW - 1))) << 4)) = w;
             }
+        const int cc = lane & (CPRW - 1);
+        char* obase = (char*)((OT*)p.o + (int64_t)b * p.o_sb + (int64_t)hh * p.o_sh) + 16 * cc;
+#pragma unroll
+        for (int i = 0; i < 32 / RPI; ++i) {
+            const int row = RPI * i + lane / CPRW;
+            const u32x4 x = *(const lds_u32x4_t*)(uintptr_t)(lbase + row * RB + ((cc ^ (row & (CPRW - 1))) << 4));
+            if (wave_q0 + row < p.Sq) *(u32x4*)(obase + (int64_t)(wave_q0 + row) * p.o_ss * 2) = x;
+        }
     } else if (my_q < p.Sq) {
         OT* orow = (OT*)p.o + (int64_t)b * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)my_q * p.o_ss;
 #pragma unroll
