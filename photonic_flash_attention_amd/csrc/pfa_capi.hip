@@ -90,11 +90,12 @@ Variant pick(const pfa_fa3_args* a) {
     const bool out32 = a->dtype_out == PFA_DTYPE_FP32;
     const unsigned var = (a->flags >> 8) & 0xffu;   // 0 = production default
     // The 4-wave x 64-row kernel (D = 128, single P, no element mask) wins once a workgroup streams enough key tiles to
-    // amortise its software-pipeline fill and drain: from Sk = 1024 on, causal or not (tools/ab_bench.py, one box:
-    // S1K +4 %, S1Kc +3 %, S2K +2 %, S2Kc +1 %, C3 +2 %, C4 +2.5 %, S8Kc +3 %, C5 +5 %; S512 -2.5 %, S512c -7 %, S256 -6 %).
+    // amortise its software-pipeline fill and drain: from ~32 tiles per workgroup on (tools/ab_bench.py, one box, both
+    // kernels with the LDS-staged epilogue: C3 +1 %, C4 +2 %, S8Kc +3 %, C5 +5 %; S2Kc -3 %, S1K -4 %, S512 -5 %).
     // Variant 43 forces it, 44 forces the 8-wave kernel (A/B).
     const bool w4_ok = a->D == 128 && !split && !kmask;
-    if (w4_ok && (var == 43 || (var == 0 && a->Sk >= 1024))) return w4_variant(a, causal, out32);
+    const int64_t avg_tiles = (causal ? (int64_t)a->Sk / 2 : (int64_t)a->Sk) / pfa::BLOCK_N;
+    if (w4_ok && (var == 43 || (var == 0 && avg_tiles >= 32))) return w4_variant(a, causal, out32);
     if (var != 0 && var != 44 && a->dtype_in == PFA_DTYPE_BF16 && a->D == 128 && !split && !kmask && !out32) {
         switch (var) {
             case 1: return exp_variant<pfa::VAR_SCHED | pfa::VAR_GLDS | pfa::VAR_BUFDMA>(causal);          // exact lazy rescale (no defer-max)
