@@ -69,7 +69,8 @@ __global__ __launch_bounds__(256) void fa3_weights_kernel(const WeightsParams p)
     const float lse2 = lse * 1.4426950408889634f;      // -inf for a fully masked row -> weights 0 below
     const bool dead_row = !(lse > -INFINITY);
 
-    for (int key_base = 0; key_base < kv_end; key_base += 32) {
+    // one 32-key block of S^T = K Q^T -> weights of this lane's row, keys key_base + (e&3) + 8(e>>2) + 4h
+    auto block = [&](int key_base, float (&w)[16]) {
         f32x16 s;
 #pragma unroll
         for (int e = 0; e < 16; ++e) s[e] = 0.f;
@@ -77,33 +78,78 @@ __global__ __launch_bounds__(256) void fa3_weights_kernel(const WeightsParams p)
         const T* ksrc = kp + (int64_t)krow * p.k_ss + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) s = E::mfma(*(const v8*)(ksrc + 16 * ks), qf[ks], s);
-        // lane (r,h) now holds S[my_q][key_base + (e&3) + 8(e>>2) + 4h]
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int key0 = key_base + 8 * g + 4 * h;
-            float w4[4];
+        for (int e = 0; e < 16; ++e) {
+            const int key = key_base + (e & 3) + 8 * (e >> 2) + 4 * h;
+            bool ok = key < kv_len && !dead_row;
+            if (CAUSAL) ok = ok && (key <= my_q);
+            if (KMASK) ok = ok && (mp[(int64_t)min(key, p.Sk - 1) * p.m_sk] != 0);
+            w[e] = ok ? fast_exp2(__builtin_fmaf(s[e], c, -lse2)) : 0.f;
+        }
+    };
+
+    // Fast path, 64 keys at a time: the wave's 32 x 64 block goes through LDS (one [32 rows][64 * sizeof(WT)] image per
+    // wave, 16-byte units XOR-swizzled by the row) and leaves as WHOLE 128- or 256-byte row segments, 8 or 4 rows per
+    // store instruction -- the per-lane form below writes 8/16-byte pieces at the row stride (half a cache line per row
+    // and key block) and ran at 1.2-2.4 TB/s.
+    constexpr int ES = sizeof(WT), CB = 4 * ES, RB = 64 * ES, NU = RB / 16, RPI = 64 / NU;
+    __shared__ __attribute__((aligned(16))) char wbuf[4 * 32 * RB];
+    typedef __attribute__((address_space(3))) char lchar;
+    lchar* const lbase = (lchar*)wbuf + wave * (32 * RB);
+    const bool vec_ok = ((p.w_sq * ES) % 16 == 0) && ((reinterpret_cast<uintptr_t>(p.w) + (p.w_sb * b + p.w_sh * hh) * ES) % 16 == 0);
+    int key_base = 0;
+    if (vec_ok) {
+        char* const wbase = (char*)((WT*)p.w + (int64_t)b * p.w_sb + (int64_t)hh * p.w_sh);
+        for (; key_base + 64 <= p.Sk && key_base < kv_end; key_base += 64) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int key = key0 + e;
-                bool ok = key < kv_len && !dead_row;
-                if (CAUSAL) ok = ok && (key <= my_q);
-                if (KMASK) ok = ok && (mp[(int64_t)min(key, p.Sk - 1) * p.m_sk] != 0);
-                w4[e] = ok ? fast_exp2(__builtin_fmaf(s[4 * g + e], c, -lse2)) : 0.f;
-            }
-            if (my_q < p.Sq) {
-                if (key0 + 3 < p.Sk && ((reinterpret_cast<uintptr_t>(wrow + key0) & (4 * sizeof(WT) - 1)) == 0)) {
-                    if constexpr (sizeof(WT) == 4) {
-                        *(f32x4*)(wrow + key0) = f32x4{w4[0], w4[1], w4[2], w4[3]};
+            for (int kb = 0; kb < 2; ++kb) {
+                float w[16];
+                block(key_base + 32 * kb, w);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ci = 8 * kb + 2 * g + h;                  // 4-element chunk of the 64-key row
+                    const int u = (ci * CB) >> 4, uo = (ci * CB) & 15;  // its 16-byte unit and the offset inside
+                    lchar* dst = lbase + r * RB + ((u ^ (r & (NU - 1))) << 4) + uo;
+                    if constexpr (ES == 4) {
+                        *(__attribute__((address_space(3))) f32x4*)dst = f32x4{w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]};
                     } else {
                         typename E::v4 t;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) t[e] = (T)w4[e];
+                        for (int e = 0; e < 4; ++e) t[e] = (T)w[4 * g + e];
+                        *(__attribute__((address_space(3))) typename E::v4*)dst = t;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 32 / RPI; ++i) {
+                const int row = RPI * i + lane / NU, u = lane % NU;
+                const u32x4 x = *(const __attribute__((address_space(3))) u32x4*)(lbase + row * RB + ((u ^ (row & (NU - 1))) << 4));
+                if (wave_q0 + row < p.Sq)
+                    *(u32x4*)(wbase + ((int64_t)(wave_q0 + row) * p.w_sq + key_base) * ES + 16 * u) = x;
+            }
+        }
+    }
+    // remaining key blocks (tails, unaligned rows): per-lane stores
+    for (; key_base < kv_end; key_base += 32) {
+        float w[16];
+        block(key_base, w);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int key0 = key_base + 8 * g + 4 * h;
+            if (my_q < p.Sq) {
+                if (key0 + 3 < p.Sk && ((reinterpret_cast<uintptr_t>(wrow + key0) & (4 * sizeof(WT) - 1)) == 0)) {
+                    if constexpr (sizeof(WT) == 4) {
+                        *(f32x4*)(wrow + key0) = f32x4{w[4 * g], w[4 * g + 1], w[4 * g + 2], w[4 * g + 3]};
+                    } else {
+                        typename E::v4 t;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) t[e] = (T)w[4 * g + e];
                         *(typename E::v4*)(wrow + key0) = t;
                     }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (key0 + e < p.Sk) wrow[key0 + e] = (WT)w4[e];
+                        if (key0 + e < p.Sk) wrow[key0 + e] = (WT)w[4 * g + e];
                 }
             }
         }
