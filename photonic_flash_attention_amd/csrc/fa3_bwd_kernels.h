@@ -173,6 +173,44 @@ struct TileRead {
     }
 };
 
+// A wave's 32 x D fp32 tile held row-per-lane-pair (acc[db][4g+e] = element d = 32 db + 8 g + 4 h + e of row r), scaled,
+// converted to 16 bits and written to global memory as WHOLE rows through LDS: lane pairs first form 16-byte chunks
+// (v_permlane32_swap), the tile is laid out [32 rows][D*2 B] with the chunk index XOR-swizzled by the row, and is read
+// back so that one store instruction covers 4 (D = 128) or 8 (D = 64) full rows (fa3_fwd_kernel.h epilogue; the per-lane
+// form touches 64 cache lines per instruction).  `lbase`: this wave's private 32*D*2-byte LDS region, free to use.
+template <typename T, int D>
+__device__ __forceinline__ void store_tile_rows_via_lds(const f32x16 (&acc)[D / 32], float mul, uint32_t lbase, int lane,
+                                                        char* grow0, int64_t row_stride_bytes, int rows_valid) {
+    using v4 = typename Elem<T>::v4;
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4_t;
+    constexpr int RB = D * 2, CPRW = RB / 16, RPI = 64 / CPRW;
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+            v4 wa, wb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                wa[e] = (T)(acc[db][4 * g + e] * mul);
+                wb[e] = (T)(acc[db][4 * g + 4 + e] * mul);
+            }
+            const u32x2 ua = __builtin_bit_cast(u32x2, wa), ub = __builtin_bit_cast(u32x2, wb);
+            auto r0 = __builtin_amdgcn_permlane32_swap(ua[0], ub[0], false, false);
+            auto r1 = __builtin_amdgcn_permlane32_swap(ua[1], ub[1], false, false);
+            const u32x4 w = {r0[0], r1[0], r0[1], r1[1]};
+            const uint32_t ch = 4 * db + g + h;
+            *(lds_u32x4_t*)(uintptr_t)(lbase + r * RB + ((ch ^ (r & (CPRW - 1))) << 4)) = w;
+        }
+    const int cc = lane & (CPRW - 1);
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+        const int row = RPI * i + lane / CPRW;
+        const u32x4 x = *(const lds_u32x4_t*)(uintptr_t)(lbase + row * RB + ((cc ^ (row & (CPRW - 1))) << 4));
+        if (row < rows_valid) *(u32x4*)(grow0 + (int64_t)row * row_stride_bytes + 16 * cc) = x;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // dQ: forward geometry.  LDS stage = [K image | V image], double buffered (64 KiB at D = 128).
 template <typename T, int D, bool CAUSAL, bool KMASK, typename OT>
@@ -330,24 +368,19 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
         step(IC<0>{}, j);
         if (j + 1 < nt) step(IC<1>{}, j + 1);
     }
-    if (my_q < p.Sq) {
+    if constexpr (sizeof(OT) == 2) {     // LDS is free after the loop's last barrier
+        char* g0 = (char*)((OT*)p.dq + (int64_t)b * p.dq_sb + (int64_t)hh * p.dq_sh + (int64_t)wave_q0 * p.dq_ss);
+        store_tile_rows_via_lds<T, D>(acc, p.scale, smem_base + wave * (32 * D * 2), lane, g0, p.dq_ss * 2, p.Sq - wave_q0);
+    } else if (my_q < p.Sq) {
         OT* orow = (OT*)p.dq + (int64_t)b * p.dq_sb + (int64_t)hh * p.dq_sh + (int64_t)my_q * p.dq_ss;
 #pragma unroll
         for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int d = db * 32 + 8 * g + 4 * h;
-                if constexpr (sizeof(OT) == 4) {
-                    f32x4 w;
+                f32x4 w;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) w[e] = acc[db][4 * g + e] * p.scale;
-                    *(f32x4*)(orow + d) = w;
-                } else {
-                    v4 w;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) w[e] = (T)(acc[db][4 * g + e] * p.scale);
-                    *(v4*)(orow + d) = w;
-                }
+                for (int e = 0; e < 4; ++e) w[e] = acc[db][4 * g + e] * p.scale;
+                *(f32x4*)(orow + db * 32 + 8 * g + 4 * h) = w;
             }
     }
 }
@@ -557,7 +590,13 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
                 dv[i][e] = 0.f;
             }
     }
-    if (my_key < p.Sk) {
+    if constexpr (sizeof(OT) == 2) {     // LDS is free after the loop's last barrier; dK then dV through the same region
+        const uint32_t lb = smem_base + wave * (32 * D * 2);
+        char* gk = (char*)((OT*)p.dk + (int64_t)b * p.dk_sb + (int64_t)hh * p.dk_sh + (int64_t)wave_k0 * p.dk_ss);
+        char* gv = (char*)((OT*)p.dv + (int64_t)b * p.dv_sb + (int64_t)hh * p.dv_sh + (int64_t)wave_k0 * p.dv_ss);
+        store_tile_rows_via_lds<T, D>(dk, p.scale, lb, lane, gk, p.dk_ss * 2, p.Sk - wave_k0);
+        store_tile_rows_via_lds<T, D>(dv, 1.0f, lb, lane, gv, p.dv_ss * 2, p.Sk - wave_k0);
+    } else if (my_key < p.Sk) {
         OT* krow_o = (OT*)p.dk + (int64_t)b * p.dk_sb + (int64_t)hh * p.dk_sh + (int64_t)my_key * p.dk_ss;
         OT* vrow_o = (OT*)p.dv + (int64_t)b * p.dv_sb + (int64_t)hh * p.dv_sh + (int64_t)my_key * p.dv_ss;
 #pragma unroll
@@ -565,25 +604,14 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d = db * 32 + 8 * g + 4 * h;
-                if constexpr (sizeof(OT) == 4) {
-                    f32x4 wk, wv;
+                f32x4 wk, wv;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        wk[e] = dk[db][4 * g + e] * p.scale;
-                        wv[e] = dv[db][4 * g + e];
-                    }
-                    *(f32x4*)(krow_o + d) = wk;
-                    *(f32x4*)(vrow_o + d) = wv;
-                } else {
-                    v4 wk, wv;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        wk[e] = (T)(dk[db][4 * g + e] * p.scale);
-                        wv[e] = (T)dv[db][4 * g + e];
-                    }
-                    *(v4*)(krow_o + d) = wk;
-                    *(v4*)(vrow_o + d) = wv;
+                for (int e = 0; e < 4; ++e) {
+                    wk[e] = dk[db][4 * g + e] * p.scale;
+                    wv[e] = dv[db][4 * g + e];
                 }
+                *(f32x4*)(krow_o + d) = wk;
+                *(f32x4*)(vrow_o + d) = wv;
             }
     }
 }

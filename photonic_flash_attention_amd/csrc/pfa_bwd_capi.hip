@@ -30,8 +30,8 @@ int check_bwd(const pfa_fa3_bwd_args* a) {
         if (s % 8) return PFA_ERR_STRIDE;
     const int64_t out_st[] = {a->dq_stride_b, a->dq_stride_h, a->dq_stride_s, a->dk_stride_b, a->dk_stride_h,
                               a->dk_stride_s, a->dv_stride_b, a->dv_stride_h, a->dv_stride_s};
-    for (int64_t s : out_st)
-        if (s % 4) return PFA_ERR_STRIDE;
+    for (int64_t s : out_st)      // gradient rows leave in 16-byte pieces
+        if (s % (a->dtype_grad == PFA_DTYPE_FP32 ? 4 : 8)) return PFA_ERR_STRIDE;
     const void* ptrs[] = {a->q, a->k, a->v, a->o, a->dout, a->dq, a->dk, a->dv};
     for (const void* p : ptrs)
         if (!al16(p)) return PFA_ERR_ALIGN;
