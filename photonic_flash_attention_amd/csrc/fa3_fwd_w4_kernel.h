@@ -164,14 +164,21 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
                      : "memory", "m0");
     };
     const uint32_t k_tile = (uint32_t)(BLOCK_N * 2) * (uint32_t)p.k_ss, v_tile = (uint32_t)(BLOCK_N * 2) * (uint32_t)p.v_ss;
-    const uint32_t k_step = 32u * (uint32_t)p.k_ss, v_step = 32u * (uint32_t)p.v_ss;
-    auto dma_k = [&](int j, int t) {      // piece t of K(j); rows past Sk arrive as zeros; tiles past the workgroup's last are fetched but never read
-        const uint32_t off = __builtin_amdgcn_readfirstlane(min((uint32_t)j * k_tile + (uint32_t)t * k_step, k_slab));
-        dma_piece(ksrd, koffd + off, smem_base + K_BASE + (j & 1) * TILE_BYTES + (wave + NW * t) * 1024);
+    // per-lane offsets of the four pieces of an image (piece t = 16 rows further), fixed for the kernel: a piece then costs
+    // one scalar multiply-free add (tile offset, wave-uniform) folded into ONE v_add, m0, and the load itself.  No clamp:
+    // offsets past the slab fail the descriptor's range check (nothing is written), and they cannot wrap (slab < 2 GiB).
+    uint32_t koffd_t[PPW], voffd_t[PPW];
+#pragma unroll
+    for (int t = 0; t < PPW; ++t) {
+        koffd_t[t] = koffd + (uint32_t)t * 32u * (uint32_t)p.k_ss;
+        voffd_t[t] = voffd + (uint32_t)t * 32u * (uint32_t)p.v_ss;
+        asm volatile("" : "+v"(koffd_t[t]), "+v"(voffd_t[t]));
+    }
+    auto dma_k = [&](int j, int t) {      // piece t of K(j); rows past Sk arrive as zeros; tiles past the workgroup's last are skipped by the range check or fetched and never read
+        dma_piece(ksrd, koffd_t[t] + (uint32_t)j * k_tile, smem_base + K_BASE + (j & 1) * TILE_BYTES + (wave + NW * t) * 1024);
     };
     auto dma_v = [&](int j, int t) {
-        const uint32_t off = __builtin_amdgcn_readfirstlane(min((uint32_t)j * v_tile + (uint32_t)t * v_step, v_slab));
-        dma_piece(vsrd, voffd + off, smem_base + V_BASE + (j & 1) * TILE_BYTES + (wave + NW * t) * 1024);
+        dma_piece(vsrd, voffd_t[t] + (uint32_t)j * v_tile, smem_base + V_BASE + (j & 1) * TILE_BYTES + (wave + NW * t) * 1024);
     };
 
     // ---- per-lane LDS read addresses (opaque: see VAR_DIET in fa3_fwd_kernel.h) ---------------------------------------------
