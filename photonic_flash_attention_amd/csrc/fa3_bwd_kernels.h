@@ -151,7 +151,10 @@ struct TileRead {
     __device__ __forceinline__ void init(int lane, uint32_t base) {
         const int r = lane & 31, h = lane >> 5;
 #pragma unroll
-        for (int ks = 0; ks < (LEAN ? 1 : KS); ++ks) row_off[ks] = base + tile_off<D>(r, 2 * ks + h);
+        for (int ks = 0; ks < (LEAN ? 1 : KS); ++ks) {
+            row_off[ks] = base + tile_off<D>(r, 2 * ks + h);
+            asm volatile("" : "+v"(row_off[ks]));      // opaque: hipcc otherwise keeps row and chunk parts apart and re-adds them per tile
+        }
         const int g1 = (lane >> 4) & 1, tq = (lane & 15) >> 2, tp = lane & 3;
 #pragma unroll
         for (int s2 = 0; s2 < (LEAN ? 1 : NS2); ++s2)
@@ -159,7 +162,10 @@ struct TileRead {
             for (int db = 0; db < (LEAN ? 1 : DB); ++db)
 #pragma unroll
                 for (int hi = 0; hi < 2; ++hi)
+                {
                     tr_off[s2][db][hi] = base + tile_off<D>(16 * s2 + 4 * h + tq + 8 * hi, db * 4 + 2 * g1 + (tp >> 1)) + 8 * (tp & 1);
+                    asm volatile("" : "+v"(tr_off[s2][db][hi]));
+                }
     }
     template <int KSI>
     __device__ __forceinline__ uint32_t row_at() const {
@@ -172,6 +178,20 @@ struct TileRead {
         else return tr_off[S2][DBI][HI];
     }
 };
+
+// eight fp32 -> one 8 x 16-bit MFMA operand as four pair conversions (v_cvt_pk_bf16_f32 for bf16): written element by
+// element, hipcc converts singly and re-packs with v_alignbit / v_mov (48 instead of 16 instructions per 32 values)
+template <typename T>
+__device__ __forceinline__ typename Elem<T>::v8 pack8(const float (&x)[8]) {
+    typedef __attribute__((ext_vector_type(2))) T t2;
+    u32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const t2 t = {(T)x[2 * i], (T)x[2 * i + 1]};
+        r[i] = __builtin_bit_cast(uint32_t, t);
+    }
+    return __builtin_bit_cast(typename Elem<T>::v8, r);
+}
 
 // A wave's 32 x D fp32 tile held row-per-lane-pair (acc[db][4g+e] = element d = 32 db + 8 g + 4 h + e of row r), scaled,
 // converted to 16 bits and written to global memory as WHOLE rows through LDS: lane pairs first form 16-byte chunks
@@ -327,9 +347,10 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                v8 ds;
+                float dsx[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) ds[e] = (T)s[kb][8 * s2 + e];
+                for (int e = 0; e < 8; ++e) dsx[e] = s[kb][8 * s2 + e];
+                const v8 ds = pack8<T>(dsx);
                 constexpr int S2I = (D == 128) ? 0 : 1;
                 const int koffs = BOFF + kb * HALF_TILE + ((D == 128) ? s2 * 16 * 256 : 0);
 #pragma unroll
@@ -514,14 +535,14 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
             constexpr int s2 = decltype(s2c)::value;
             constexpr int S2I = (D == 128) ? 0 : s2;
             constexpr int koffs = BOFF + HOFF + ((D == 128) ? s2 * 16 * 256 : 0);
-            v8 pb, dsb;
+            float px[8], dx[8];
 #pragma unroll
             for (int e8 = 0; e8 < 8; ++e8) {
                 const int e = 8 * s2 + e8;
-                const float pe = fast_exp2(s[e] * c);       // exp(scale*S - lse); rows staged as -inf and masked entries give 0
-                pb[e8] = (T)pe;
-                dsb[e8] = (T)(pe * dpv[e]);
+                px[e8] = fast_exp2(s[e] * c);               // exp(scale*S - lse); rows staged as -inf and masked entries give 0
+                dx[e8] = px[e8] * dpv[e];
             }
+            const v8 pb = pack8<T>(px), dsb = pack8<T>(dx);
             static_for<DB>([&](auto dbc) {
                 constexpr int db = decltype(dbc)::value;
                 const uint32_t t0 = rq.template tr_at<S2I, db, 0>(), t1 = rq.template tr_at<S2I, db, 1>();
