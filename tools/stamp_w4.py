@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Phase stamps of the 4-wave x 64-row forward (variant 43 built with -DPFA_W4_STAMP): cycles per wave-tile."""
+"""Phase stamps of the 4-wave x 64-row forward: cycles per wave-tile.  Needs the diagnostic build of the library
+(`make -C photonic_flash_attention_amd/csrc clean && make -C photonic_flash_attention_amd/csrc W4FLAGS=-DPFA_W4_STAMP`);
+rebuild without the flag afterwards -- a stamped kernel is ~10 % slower and must never be benchmarked."""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from photonic_flash_attention_amd import ops, _capi
