@@ -6,6 +6,8 @@ Counterpart of the reference's ``integration/pytorch/convert.py`` (``ModelConver
 * handled: ``torch.nn.MultiheadAttention`` with a packed ``in_proj_weight`` (the PyTorch rule of the reference,
   :441-452: ``in_proj_weight -> qkv_proj.weight``, ``in_proj_bias -> qkv_proj.bias``, ``out_proj`` copied), found
   anywhere in the module tree and replaced in place, e.g. inside ``nn.TransformerEncoderLayer``;
+* handled: Hugging Face ``transformers`` model OBJECTS (BERT, GPT-2, Llama-style ...) by registering the kernel as an
+  attention implementation (``hf.py``) -- the counterpart of the reference's per-architecture weight copies (:389-450);
 * not handled (reported in ``skipped_layers``): ``kdim/vdim`` != ``embed_dim``, ``add_bias_kv``, ``add_zero_attn``;
 * a model *name* (string) would mean ``AutoModel.from_pretrained`` = a network fetch (reference :545): refused.
 
@@ -97,6 +99,13 @@ def convert_to_photonic(model, dtype: Optional[torch.dtype] = None, inplace: boo
     report = ConversionReport(original_model_name=type(model).__name__)
     if not inplace:
         model = copy.deepcopy(model)
+    if hasattr(getattr(model, "config", None), "_attn_implementation"):
+        # a transformers model OBJECT: its attention goes through the pluggable function table (integration/pytorch/hf.py);
+        # weights stay where they are, so none of the reference's per-architecture copy rules (:389-450) is needed
+        from .hf import convert_hf_model, IMPLEMENTATION_NAME
+        convert_hf_model(model)
+        report.converted_layers.append(f"<all attention layers via attn_implementation={IMPLEMENTATION_NAME!r}>")
+        return model, report
     if isinstance(model, nn.MultiheadAttention):
         targets = [("", None, model)]
     else:

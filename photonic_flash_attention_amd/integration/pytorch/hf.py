@@ -1,0 +1,77 @@
+"""Hugging Face models on the MI355X attention kernels, without touching their modules.
+
+The reference converts HF models by swapping attention layers and copying weights by name
+(``integration/pytorch/convert.py:389-450``: BERT ``query/key/value``, GPT-2 ``c_attn/c_proj``, T5 ``q/k/v/o``), and
+loads them by name from the hub (``:545``).  Current ``transformers`` (>= 4.48; 5.x here) route every model's attention
+through a pluggable function table instead (``transformers.AttentionInterface``): a model whose
+``config._attn_implementation`` names a registered function calls it with ``query/key/value`` already projected and
+split into heads.  Registering the HIP kernel there converts BERT, GPT-2, Llama-style models ... alike, keeps their
+weights where they are, and is autograd-aware through ``ops.fa3_attention``.
+
+Only model OBJECTS are handled (``convert_hf_model(model)``); nothing is ever fetched from the network.
+"""
+
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from ... import ops
+
+IMPLEMENTATION_NAME = "pfa_hip"
+
+
+def _keep_mask(attention_mask: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """HF hands sdpa-style masks: bool (True = attend) or float additive (0 = attend, large negative = masked)."""
+    if attention_mask is None:
+        return None
+    if attention_mask.dtype == torch.bool:
+        return attention_mask
+    return attention_mask > -1.0          # additive masks are 0 or <= -1e4 / finfo.min / -inf
+
+
+def pfa_attention_forward(module, query, key, value, attention_mask, dropout: float = 0.0,
+                          scaling: Optional[float] = None, is_causal: Optional[bool] = None, **kwargs):
+    """``AttentionInterface`` function: ``query/key/value`` are ``[B, H(kv), S, D]``; returns ``([B, Sq, H, D], None)``.
+
+    Mirrors ``transformers.integrations.sdpa_attention.sdpa_attention_forward`` (same causal rule: the flag is used only
+    when no mask tensor is given and there is more than one query position)."""
+    if kwargs.get("output_attentions", False):
+        raise NotImplementedError(f"'{IMPLEMENTATION_NAME}' attention does not return attention weights; use 'eager'")
+    if dropout and getattr(module, "training", False):
+        raise NotImplementedError("attention dropout in training mode is not implemented on the HIP path")
+    groups = getattr(module, "num_key_value_groups", 1)
+    if groups > 1:                         # grouped-query attention: the kernel wants one K/V head per query head
+        key = key.repeat_interleave(groups, dim=1)
+        value = value.repeat_interleave(groups, dim=1)
+    if query.shape[-1] not in (64, 128):
+        raise NotImplementedError(f"head_dim {query.shape[-1]} has no kernel (64, 128)")
+    q_len = query.shape[2]
+    causal = is_causal if is_causal is not None else getattr(module, "is_causal", True)
+    causal = bool(q_len > 1 and attention_mask is None and causal)
+    keep = _keep_mask(attention_mask)
+    in_dtype = query.dtype
+    cd = in_dtype if in_dtype in (torch.bfloat16, torch.float16) else torch.bfloat16
+    out = ops.fa3_attention(query.to(cd), key.to(cd), value.to(cd), causal=causal, mask=keep, softmax_scale=scaling,
+                            out_dtype=in_dtype)
+    return out.transpose(1, 2), None       # [B,H,S,D] view of a [B,S,H,D] buffer -> contiguous [B,S,H,D]
+
+
+def register_hf_attention(name: str = IMPLEMENTATION_NAME) -> str:
+    """Register the kernel as a ``transformers`` attention implementation (idempotent).  Masks are built like sdpa's."""
+    from transformers import AttentionInterface, AttentionMaskInterface
+    from transformers.masking_utils import sdpa_mask
+    AttentionInterface.register(name, pfa_attention_forward)
+    AttentionMaskInterface.register(name, sdpa_mask)
+    return name
+
+
+def convert_hf_model(model, name: str = IMPLEMENTATION_NAME):
+    """Switch a ``transformers.PreTrainedModel`` OBJECT to the HIP attention path in place and return it."""
+    register_hf_attention(name)
+    if hasattr(model, "set_attn_implementation"):
+        model.set_attn_implementation(name)
+    else:                                   # older transformers
+        model.config._attn_implementation = name
+    return model

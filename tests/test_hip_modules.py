@@ -202,3 +202,47 @@ def test_forward_is_capturable_in_a_hip_graph():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, eager)
+
+
+def test_hugging_face_models_run_on_the_kernel():
+    """transformers model OBJECTS (random weights built offline from a config) switched to the HIP attention function:
+    BERT (bidirectional, padding mask) and GPT-2 (causal) reproduce their own sdpa outputs within the bf16-operand
+    tolerance, and train (gradients reach the embeddings)."""
+    transformers = pytest.importorskip("transformers")
+    from photonic_flash_attention_amd import convert_to_photonic
+    torch.manual_seed(0)
+    cfg = transformers.BertConfig(hidden_size=256, num_attention_heads=4, num_hidden_layers=2, intermediate_size=512,
+                                  vocab_size=500, max_position_embeddings=256)
+    bert = transformers.BertModel(cfg).to(DEV).eval()
+    ids = torch.randint(0, 500, (2, 200), device=DEV)
+    am = torch.ones(2, 200, dtype=torch.long, device=DEV)
+    am[1, 150:] = 0
+    with torch.no_grad():
+        ref = bert(input_ids=ids, attention_mask=am).last_hidden_state
+    conv, report = convert_to_photonic(bert)
+    assert report.converted_layers and conv.config._attn_implementation == "pfa_hip"
+    with torch.no_grad():
+        got = conv(input_ids=ids, attention_mask=am).last_hidden_state
+    valid = am.bool()
+    err = float((got - ref)[valid].abs().max())
+    print(f"BERT (2 layers) vs its sdpa path: max-abs {err:.3e}")
+    assert err <= 5e-2 and bool(torch.isfinite(got).all())
+    conv.train()
+    for m_ in conv.modules():
+        if isinstance(m_, torch.nn.Dropout):
+            m_.p = 0.0
+    out = conv(input_ids=ids, attention_mask=am).last_hidden_state
+    out[valid].square().mean().backward()
+    g = conv.embeddings.word_embeddings.weight.grad
+    assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().sum()) > 0
+
+    gcfg = transformers.GPT2Config(n_embd=256, n_head=4, n_layer=2, vocab_size=500, n_positions=512, bos_token_id=0, eos_token_id=1)
+    gpt = transformers.GPT2Model(gcfg).to(DEV).eval()
+    ids2 = torch.randint(0, 500, (2, 300), device=DEV)
+    with torch.no_grad():
+        ref2 = gpt(input_ids=ids2).last_hidden_state
+        conv2, _ = convert_to_photonic(gpt)
+        got2 = conv2(input_ids=ids2).last_hidden_state
+    err2 = float((got2 - ref2).abs().max())
+    print(f"GPT-2 (2 layers) vs its sdpa path: max-abs {err2:.3e}")
+    assert err2 <= 5e-2

@@ -276,3 +276,25 @@ def test_integration_md_binding_matches_the_abi():
     doc = ns["PfaFa3Args"]
     assert [f[0] for f in doc._fields_] == [f[0] for f in _capi.PfaFa3Args._fields_]
     assert C.sizeof(doc) == C.sizeof(_capi.PfaFa3Args)
+
+
+def test_hf_attention_registration_and_mask_dialect():
+    """transformers models take the kernel through AttentionInterface; on a CPU tensor the call fails loudly (no fallback)."""
+    transformers = pytest.importorskip("transformers")
+    import torch
+    from photonic_flash_attention_amd.integration.pytorch import hf
+    from photonic_flash_attention_amd.integration.pytorch.convert import convert_to_photonic
+    name = hf.register_hf_attention()
+    assert name in transformers.AttentionInterface().valid_keys()
+    assert hf._keep_mask(None) is None
+    b = torch.tensor([[True, False]])
+    assert hf._keep_mask(b) is b
+    add = torch.tensor([[0.0, -1e4, float("-inf"), torch.finfo(torch.float32).min]])
+    assert hf._keep_mask(add).tolist() == [[True, False, False, False]]
+    cfg = transformers.BertConfig(hidden_size=256, num_attention_heads=4, num_hidden_layers=1, intermediate_size=256, vocab_size=50)
+    model = transformers.BertModel(cfg).eval()
+    conv, report = convert_to_photonic(model)
+    assert conv is not model and conv.config._attn_implementation == hf.IMPLEMENTATION_NAME
+    assert model.config._attn_implementation != hf.IMPLEMENTATION_NAME and report.converted_layers
+    with torch.no_grad(), pytest.raises((ValueError, RuntimeError)):
+        conv(input_ids=torch.tensor([[1, 2, 3, 4]]))
