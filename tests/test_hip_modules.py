@@ -246,3 +246,21 @@ def test_hugging_face_models_run_on_the_kernel():
     err2 = float((got2 - ref2).abs().max())
     print(f"GPT-2 (2 layers) vs its sdpa path: max-abs {err2:.3e}")
     assert err2 <= 5e-2
+
+
+def test_hugging_face_llama_style_gqa_model():
+    """A Llama-style decoder (rotary embeddings, grouped-query attention: 4 query heads on 2 K/V heads, head_dim 64)."""
+    transformers = pytest.importorskip("transformers")
+    from photonic_flash_attention_amd import convert_to_photonic
+    torch.manual_seed(1)
+    cfg = transformers.LlamaConfig(hidden_size=256, num_attention_heads=4, num_key_value_heads=2, num_hidden_layers=2,
+                                   intermediate_size=512, vocab_size=500, max_position_embeddings=1024)
+    model = transformers.LlamaModel(cfg).to(DEV).eval()
+    ids = torch.randint(0, 500, (2, 384), device=DEV)
+    with torch.no_grad():
+        ref = model(input_ids=ids).last_hidden_state
+        conv, _ = convert_to_photonic(model)
+        got = conv(input_ids=ids).last_hidden_state
+    err = float((got - ref).abs().max())
+    print(f"Llama-style (2 layers, GQA) vs its sdpa path: max-abs {err:.3e}")
+    assert err <= 5e-2 and bool(torch.isfinite(got).all())
