@@ -95,9 +95,9 @@ def tiled_attention(q, k, v, mask: Optional[torch.Tensor] = None, tile: int = 51
     for i in range(0, Sq, tile):
         ie = min(i + tile, Sq)
         qi = q[:, :, i:ie]
-        m = torch.full((B, H, ie - i), float("-inf"), dtype=q.dtype)
-        l = torch.zeros((B, H, ie - i), dtype=q.dtype)
-        o = torch.zeros((B, H, ie - i, D), dtype=q.dtype)
+        m = torch.full((B, H, ie - i), float("-inf"), dtype=q.dtype, device=q.device)
+        l = torch.zeros((B, H, ie - i), dtype=q.dtype, device=q.device)
+        o = torch.zeros((B, H, ie - i, D), dtype=q.dtype, device=q.device)
         for j in range(0, Sk, tile):
             je = min(j + tile, Sk)
             s = torch.matmul(qi, k[:, :, j:je].transpose(-2, -1))

@@ -293,3 +293,35 @@ def test_w4_variant_random_shapes_against_the_8_wave_kernel():
         dead = torch.isinf(l0)
         assert torch.equal(dead, torch.isinf(l1)), tag
         assert float((l0 - l1)[~dead].abs().max() if bool((~dead).any()) else 0.0) <= 3e-5, tag
+
+
+def test_speedup_over_the_eager_tiled_loop_on_this_gpu():
+    """Orientation, not a parity test: the reference's two-level tile loop (`flash_attention_3.py:182-262`, here the oracle's
+    restatement of it executed as eager torch ops on bf16 device tensors, which is what the reference does on a GPU) against
+    one launch of the HIP kernel at the headline shape C3.  The reference has no causal skipping and materialises a
+    [B,1,S,S] mask; its bf16 accumulators make it 1e-2 off, so only a loose agreement is checked."""
+    import time
+    from oracle import fa3_oracle as orc
+    from photonic_flash_attention_amd import ops, synth
+    B, H, S, D = 4, 16, 4096, 128
+    q, k, v = (t.to("cuda:0").permute(0, 2, 1, 3) for t in synth.qkv(B, H, S, S, D, 2003, "bf16"))
+    mask = torch.tril(torch.ones(S, S, dtype=torch.bool, device="cuda:0")).view(1, 1, S, S).expand(B, 1, S, S)
+    qs = q * D ** -0.5
+    ref = orc.tiled_attention(qs, k, v, mask, 512)                    # warm-up
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ref = orc.tiled_attention(qs, k, v, mask, 512)
+    torch.cuda.synchronize()
+    t_eager = time.perf_counter() - t0
+    out = ops.fa3_forward(q, k, v, causal=True)[0]
+    for _ in range(20):
+        ops.fa3_forward(q, k, v, causal=True, out=out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        ops.fa3_forward(q, k, v, causal=True, out=out)
+    torch.cuda.synchronize()
+    t_kernel = (time.perf_counter() - t0) / 50
+    print(f"C3: eager tiled loop {t_eager * 1e3:.1f} ms, HIP kernel {t_kernel * 1e3:.3f} ms -> {t_eager / t_kernel:.0f} x")
+    assert float((out.float() - ref.float()).abs().max()) <= 6e-2
+    assert t_eager / t_kernel >= 20
