@@ -7,10 +7,11 @@
 //    (and ds_read instructions) per MFMA of the 8-wave x 32-row kernel, which is power- and issue-limited by exactly that
 //    (profiles/r01_ablation_lds_vs_mfma.txt);
 //  * there is no partner wave on the SIMD, so the softmax is software-pipelined inside the wave's own stream and
-//    hand-placed between the MFMAs (sched_barrier after every step; at most ~5 vector issues per MFMA):
+//    hand-placed between the MFMAs: a tile is 64 half-steps of ONE MFMA + at most ~5 vector issues each, with a
+//    sched_barrier behind the MFMA and behind its filler (two MFMAs back to back stall the in-order wave on the second):
 //
-//        iteration j :  phase A   S(j+1) = K(j+1) Q^T   (32 MFMA)  ||  finish softmax(j) -> P(j)            || K reads, V DMA
-//                       phase B   O     += V(j)^T P(j)  (32 MFMA)  ||  start softmax(j+1) (max, exps of kb 0) || V^T reads, K DMA
+//        iteration j :  phase A   S(j+1) = K(j+1) Q^T   (32 MFMA)  ||  finish softmax(j) -> P(j)            || K reads, all 8 DMA pieces
+//                       phase B   O     += V(j)^T P(j)  (32 MFMA)  ||  start softmax(j+1) (max, exps of kb 0) || V^T reads
 //
 //    S is double-buffered in registers (2 x 64 VGPRs); O (128) and Q (64) live in the accumulator half of the register
 //    file and are touched only by inline-asm MFMAs ("a" constraints), so hipcc never copies them through VGPRs.
