@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define PFA_ABI_VERSION 3
+#define PFA_ABI_VERSION 4
 
 typedef enum pfa_status {
     PFA_OK = 0,
@@ -106,6 +106,13 @@ typedef struct pfa_fa3_args {
      * `causal` and `seqlens_k` combine with either. */
     const uint8_t* mask;
     int64_t mask_stride_b, mask_stride_h, mask_stride_q, mask_stride_k;
+
+    /* ABI v4: grouped-query attention (not in the reference; what Hugging Face decoder models hand over).  k and v hold
+     * H / kv_group heads and query head h reads K/V head h / kv_group, so nothing has to be expanded in memory.
+     * 0 or 1 = one K/V head per query head.  H must be a multiple of kv_group.  Forward and weights only: the
+     * backward wants expanded K/V (autograd then sums dK/dV over the group). */
+    int32_t kv_group;
+    int32_t reserved0;          /* must be 0 */
 } pfa_fa3_args;
 
 /* ABI version of the loaded library (== PFA_ABI_VERSION of the header it was built from). */

@@ -13,7 +13,7 @@ import os
 import threading
 from typing import Optional
 
-PFA_ABI_VERSION = 3
+PFA_ABI_VERSION = 4
 PFA_DTYPE_BF16, PFA_DTYPE_FP16, PFA_DTYPE_FP32 = 0, 1, 2
 PFA_FLAG_SPLIT_P = 0x1
 PFA_FLAG_NO_XCD_MAP = 0x2
@@ -46,6 +46,7 @@ class PfaFa3Args(C.Structure):
         ("mask", C.c_void_p),
         ("mask_stride_b", C.c_int64), ("mask_stride_h", C.c_int64), ("mask_stride_q", C.c_int64),
         ("mask_stride_k", C.c_int64),
+        ("kv_group", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

@@ -56,6 +56,7 @@ struct FwdParams {
     int64_t m_sb, m_sh, m_sq, m_sk;   // a 2-D [B,Sk] key mask is (stride, 0, 0, 1)
     int32_t B, H, Sq, Sk;
     int32_t nqblk;        // ceil(Sq / BLOCK_M)
+    int32_t kv_group;     // query heads per K/V head (>= 1): query head h reads K/V head h / kv_group
     float scale_log2;     // softmax_scale * log2(e)
     unsigned long long* dbg;   // VAR_STAMP only: [workgroup][wave][8] cycle sums
 };
@@ -318,8 +319,8 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
     const int nt = (kv_end + BLOCK_N - 1) / BLOCK_N;
 
     const T* __restrict__ qp = (const T*)p.q + (int64_t)b * p.q_sb + (int64_t)hh * p.q_sh;
-    const T* __restrict__ kp = (const T*)p.k + (int64_t)b * p.k_sb + (int64_t)hh * p.k_sh;
-    const T* __restrict__ vp = (const T*)p.v + (int64_t)b * p.v_sb + (int64_t)hh * p.v_sh;
+    const T* __restrict__ kp = (const T*)p.k + (int64_t)b * p.k_sb + (int64_t)(hh / p.kv_group) * p.k_sh;
+    const T* __restrict__ vp = (const T*)p.v + (int64_t)b * p.v_sb + (int64_t)(hh / p.kv_group) * p.v_sh;
     const uint8_t* __restrict__ kmp =
         KMASK ? p.mask + (int64_t)b * p.m_sb + (int64_t)hh * p.m_sh + (int64_t)min(my_q, p.Sq - 1) * p.m_sq : nullptr;
 

@@ -70,8 +70,8 @@ __global__ __launch_bounds__(512, 2) void fa3_fwd_pipe_kernel(const FwdParams p)
     const int nt = (kv_end + BLOCK_N - 1) / BLOCK_N;
 
     const T* __restrict__ qp = (const T*)p.q + (int64_t)b * p.q_sb + (int64_t)hh * p.q_sh;
-    const T* __restrict__ kp = (const T*)p.k + (int64_t)b * p.k_sb + (int64_t)hh * p.k_sh;
-    const T* __restrict__ vp = (const T*)p.v + (int64_t)b * p.v_sb + (int64_t)hh * p.v_sh;
+    const T* __restrict__ kp = (const T*)p.k + (int64_t)b * p.k_sb + (int64_t)(hh / p.kv_group) * p.k_sh;
+    const T* __restrict__ vp = (const T*)p.v + (int64_t)b * p.v_sb + (int64_t)(hh / p.kv_group) * p.v_sh;
     const uint8_t* __restrict__ kmp =
         KMASK ? p.mask + (int64_t)b * p.m_sb + (int64_t)hh * p.m_sh + (int64_t)min(my_q, p.Sq - 1) * p.m_sq : nullptr;
 

@@ -102,8 +102,8 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
     const int wnt = (wave_kv_end + BLOCK_N - 1) / BLOCK_N;                             // tiles this wave computes
 
     const T* qp = (const T*)p.q + (int64_t)b * p.q_sb + (int64_t)hh * p.q_sh;
-    const char* kp = (const char*)((const T*)p.k + (int64_t)b * p.k_sb + (int64_t)hh * p.k_sh);
-    const char* vp = (const char*)((const T*)p.v + (int64_t)b * p.v_sb + (int64_t)hh * p.v_sh);
+    const char* kp = (const char*)((const T*)p.k + (int64_t)b * p.k_sb + (int64_t)(hh / p.kv_group) * p.k_sh);
+    const char* vp = (const char*)((const T*)p.v + (int64_t)b * p.v_sb + (int64_t)(hh / p.kv_group) * p.v_sh);
 
     // ---- query-block state -----------------------------------------------------------------------------------------
     struct QB {

@@ -28,6 +28,7 @@ struct WeightsParams {
     int64_t m_sb, m_sh, m_sq, m_sk;
     int32_t B, H, Sq, Sk;
     int32_t nqblk;
+    int32_t kv_group;
     float scale_log2;
 };
 
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void fa3_weights_kernel(const WeightsParams p)
     const int kv_end = CAUSAL ? min(kv_len, wave_q0 + 32) : kv_len;   // keys any row of this wave can see
 
     const T* __restrict__ qp = (const T*)p.q + (int64_t)b * p.q_sb + (int64_t)hh * p.q_sh;
-    const T* __restrict__ kp = (const T*)p.k + (int64_t)b * p.k_sb + (int64_t)hh * p.k_sh;
+    const T* __restrict__ kp = (const T*)p.k + (int64_t)b * p.k_sb + (int64_t)(hh / p.kv_group) * p.k_sh;
     const int qrow = min(my_q, p.Sq - 1);
     const uint8_t* __restrict__ mp =
         KMASK ? p.mask + (int64_t)b * p.m_sb + (int64_t)hh * p.m_sh + (int64_t)qrow * p.m_sq : nullptr;

@@ -156,6 +156,7 @@ int check(const pfa_fa3_args* a) {
     if (a->flags & ~(PFA_FLAG_SPLIT_P | PFA_FLAG_NO_XCD_MAP | PFA_FLAG_VARIANT_MASK)) return PFA_ERR_FLAGS;
     if (!a->q || !a->k || !a->v || !a->o) return PFA_ERR_NULL;
     if (a->key_mask && a->mask) return PFA_ERR_FLAGS;
+    if (a->kv_group < 0 || a->reserved0 != 0 || (a->kv_group > 1 && a->H % a->kv_group != 0)) return PFA_ERR_SHAPE;
     if (a->B <= 0 || a->H <= 0 || a->Sq <= 0 || a->Sk <= 0) return PFA_ERR_SHAPE;
     if (a->D != 64 && a->D != 128) return PFA_ERR_HEAD_DIM;
     if (a->dtype_in != PFA_DTYPE_BF16 && a->dtype_in != PFA_DTYPE_FP16) return PFA_ERR_DTYPE;
@@ -267,6 +268,7 @@ int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream) {
     p.dbg = (unsigned long long*)a->workspace;   // only the diagnostic VAR_STAMP variant writes it
     const Variant v = pick(a);
     p.nqblk = (a->Sq + v.block_m - 1) / v.block_m;
+    p.kv_group = a->kv_group > 1 ? a->kv_group : 1;
     p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
 
     const unsigned grid = (unsigned)(p.nqblk * a->B * a->H);
@@ -314,6 +316,7 @@ int pfa_fa3_weights(const pfa_fa3_args* a, void* w, int32_t w_dtype, int64_t w_s
     p.w_sb = w_stride_b; p.w_sh = w_stride_h; p.w_sq = w_stride_q;
     p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
     p.nqblk = (a->Sq + 127) / 128;
+    p.kv_group = a->kv_group > 1 ? a->kv_group : 1;
     p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
     const bool causal = a->causal != 0, kmask = p.mask != nullptr, w32 = w_dtype == PFA_DTYPE_FP32;
     const void* fn;

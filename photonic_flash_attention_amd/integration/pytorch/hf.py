@@ -41,8 +41,12 @@ def pfa_attention_forward(module, query, key, value, attention_mask, dropout: fl
         raise NotImplementedError(f"'{IMPLEMENTATION_NAME}' attention does not return attention weights; use 'eager'")
     if dropout and getattr(module, "training", False):
         raise NotImplementedError("attention dropout in training mode is not implemented on the HIP path")
-    groups = getattr(module, "num_key_value_groups", 1)
-    if groups > 1:                         # grouped-query attention: the kernel wants one K/V head per query head
+    needs_grad = torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)
+    if key.shape[1] != query.shape[1] and needs_grad:
+        # grouped-query attention under autograd: the backward kernels want one K/V head per query head, and autograd
+        # through the expansion sums dK/dV over each group.  Without gradients the forward reads the shared heads in place
+        # (pfa_fa3_args.kv_group).
+        groups = query.shape[1] // key.shape[1]
         key = key.repeat_interleave(groups, dim=1)
         value = value.repeat_interleave(groups, dim=1)
     if query.shape[-1] not in (64, 128):

@@ -69,8 +69,9 @@ def build_args(q, k, v, out, *, causal=False, seqlens_k=None, key_mask=None, sof
                lse=None, split_p=False, variant=0, mask=None):
     """Fill a ``pfa_fa3_args`` from ``[B,H,S,D]``-shaped (arbitrarily strided) tensors."""
     B, H, Sq, D = q.shape
-    Sk = k.shape[2]
-    if k.shape != (B, H, Sk, D) or v.shape != (B, H, Sk, D):
+    Sk, Hkv = k.shape[2], k.shape[1]
+    # grouped-query attention: k, v may carry H / g heads (query head h reads K/V head h // g); nothing is expanded
+    if Hkv < 1 or H % Hkv or k.shape != (B, Hkv, Sk, D) or v.shape != (B, Hkv, Sk, D):
         raise ValueError(f"shape mismatch: q {tuple(q.shape)} k {tuple(k.shape)} v {tuple(v.shape)}")
     if out.shape != (B, H, Sq, D):
         raise ValueError("output shape mismatch")
@@ -92,6 +93,7 @@ def build_args(q, k, v, out, *, causal=False, seqlens_k=None, key_mask=None, sof
         dtype_in=_DT[q.dtype], dtype_out=_DT[out.dtype], causal=1 if causal else 0,
         softmax_scale=float(D ** -0.5 if softmax_scale is None else softmax_scale),
         device_id=q.device.index if q.device.index is not None else torch.cuda.current_device(),
+        kv_group=H // Hkv,
     )
     keep = []
     if seqlens_k is not None:
@@ -190,6 +192,9 @@ def fa3_backward(q, k, v, out, dout, lse, *, causal: bool = False, seqlens_k=Non
     the forward was called with (same conventions as ``fa3_forward``)."""
     B, H, Sq, D = q.shape
     Sk = k.shape[2]
+    if k.shape[1] != H or v.shape[1] != H:
+        raise ValueError("pfa_fa3_bwd wants one K/V head per query head: expand grouped K/V (repeat_interleave) before the "
+                         "forward when gradients are needed; autograd then sums dK/dV over each group")
     gdt = q.dtype if grad_dtype is None else grad_dtype
     if dout.stride(3) != 1:
         dout = dout.contiguous()

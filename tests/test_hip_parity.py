@@ -325,3 +325,25 @@ def test_speedup_over_the_eager_tiled_loop_on_this_gpu():
     print(f"C3: eager tiled loop {t_eager * 1e3:.1f} ms, HIP kernel {t_kernel * 1e3:.3f} ms -> {t_eager / t_kernel:.0f} x")
     assert float((out.float() - ref.float()).abs().max()) <= 6e-2
     assert t_eager / t_kernel >= 20
+
+
+@pytest.mark.parametrize("case", [(2, 8, 2, 300, 300, 64, True), (1, 8, 4, 512, 2048, 128, False), (1, 4, 1, 4096, 4096, 128, True)])
+def test_grouped_query_heads_read_in_place(case):
+    """ABI v4 `kv_group`: K/V with H / g heads, query head h reading K/V head h // g, must equal the run on K/V expanded with
+    repeat_interleave bit for bit (both forward kernels), also for the weights pass; the backward refuses grouped K/V."""
+    from photonic_flash_attention_amd import ops, synth
+    B, H, Hkv, Sq, Sk, D, causal = case
+    q = synth.qkv(B, H, Sq, Sq, D, 611, "bf16")[0].to("cuda:0").permute(0, 2, 1, 3)
+    _, k, v = (t.to("cuda:0").permute(0, 2, 1, 3) for t in synth.qkv(B, Hkv, Sk, Sk, D, 612, "bf16"))
+    ke, ve = (t.repeat_interleave(H // Hkv, dim=1) for t in (k, v))
+    for var in (44, 43) if D == 128 else (0,):
+        o_g, l_g = ops.fa3_forward(q, k, v, causal=causal, return_lse=True, _variant=var)
+        o_e, l_e = ops.fa3_forward(q, ke, ve, causal=causal, return_lse=True, _variant=var)
+        torch.cuda.synchronize()
+        assert torch.equal(o_g, o_e) and torch.equal(l_g, l_e), (case, var)
+    if Sq * Sk <= 1 << 19:
+        w_g = ops.fa3_forward(q, k, v, causal=causal, return_weights=True)[2]
+        w_e = ops.fa3_forward(q, ke, ve, causal=causal, return_weights=True)[2]
+        assert torch.equal(w_g, w_e)
+    with pytest.raises(ValueError):
+        ops.fa3_backward(q, k, v, o_g, o_g, l_g, causal=causal)
