@@ -1,6 +1,7 @@
 /*
- * pfa_hip.h -- C ABI of libpfa_hip.so: the MI355X (gfx950) Flash-Attention forward that
+ * pfa_hip.h -- C ABI of libpfa_hip.so: the MI355X (gfx950) Flash-Attention forward (and backward) that
  * replaces the body of the reference's electronic attention core.
+ * ABI history: v1 forward; v2 general masks + weights; v3 backward; v4 grouped-query heads (kv_group).
  *
  * Reference seam (danieleschmidt/Photonic-Flash-Attention, all paths under
  * src/photonic_flash_attention/):
@@ -15,6 +16,8 @@
  *   pfa_fa3_weights                    the `need_weights=True` outputs (:171,:180,:257-258)
  *   pfa_fa3_args.o strides             the `.transpose(1,2).contiguous()` copy at :107 (the kernel writes
  *                                     [B,S,H,D] directly, so the copy disappears)
+ *   pfa_fa3_bwd                        autograd through :152-262 -- the reference's only backward (its modules train
+ *                                     through the eager core; tests/unit/test_flash_attention_3.py:137-160)
  *   pfa_fa3_workspace_bytes           the tile-size memory budget of :264-293 (this path needs none)
  *   pfa_device_supported              the `torch.cuda.is_available()` probes at :71,:142
  *
