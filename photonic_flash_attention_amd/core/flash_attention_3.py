@@ -133,7 +133,15 @@ class FlashAttention3(nn.Module):
                 "(this package ships no CPU or eager implementation of the core)")
         needs_grad = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)
         if self.training and self.dropout > 0:
-            raise NotImplementedError("attention dropout in training mode is not implemented on the HIP path")
+            # The reference applies attention dropout only in its dense branch (:174-175), i.e. when both sequence lengths
+            # fit one tile of min(Sq, Sk, 512) (floor 32, :264-293); its tiled branch (:182-262) has no dropout at all.
+            # Mirror that: longer sequences train with no attention dropout, exactly like the reference; the dense
+            # case has no in-kernel RNG here (it could not match the reference's random stream anyway) and is refused.
+            tile = max(32, min(q.shape[2], k.shape[2], 512))
+            if q.shape[2] <= tile and k.shape[2] <= tile:
+                raise NotImplementedError(
+                    "attention dropout in training mode is not implemented on the HIP path for sequences that fit one "
+                    "tile (<= 512); the reference applies none beyond that either")
         # 2-D [B,Sk] masks take the cheap key-mask path (:166-167); 3-D / 4-D masks the general one (:168,:235)
         key_mask = attention_mask if (attention_mask is not None and attention_mask.dim() == 2) else None
         mask = attention_mask if (attention_mask is not None and attention_mask.dim() != 2) else None

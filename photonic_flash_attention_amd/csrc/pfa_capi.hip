@@ -129,6 +129,7 @@ Variant pick(const pfa_fa3_args* a) {
             case 40: return exp_variant<pfa::VAR_DEFAULT & ~pfa::VAR_DIET>(causal);                           // before the VALU diet (reference for A/B)
             case 41: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_MFMA16>(causal);                          // timing only: 16x16x32 MFMAs
             case 42: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV | pfa::ABL_NO_DMA | pfa::ABL_NO_BARRIER | pfa::ABL_MFMA16>(causal);   // var 29 with 16x16x32
+            case 46: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_NW4>(causal);                             // 2 x 4-wave workgroups per CU, current default otherwise
             case 14: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_QKIL>(causal);
             case 15: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_PF8>(causal);
             case 17: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_QKIL | pfa::VAR_PF8>(causal);

@@ -264,3 +264,16 @@ def test_hugging_face_llama_style_gqa_model():
     err = float((got - ref).abs().max())
     print(f"Llama-style (2 layers, GQA) vs its sdpa path: max-abs {err:.3e}")
     assert err <= 5e-2 and bool(torch.isfinite(got).all())
+
+
+def test_training_dropout_follows_the_reference_branch_rule():
+    """The reference drops attention weights only in its dense branch (S <= 512, `:174-175`); its tiled branch has no
+    dropout.  A dropout > 0 module therefore trains at S = 640 (no dropout applied, as in the reference) and refuses S = 128."""
+    from photonic_flash_attention_amd import FlashAttention3
+    m = FlashAttention3(128, 2, dropout=0.1, dtype=torch.bfloat16).to(DEV).train()
+    x = torch.randn(1, 640, 128, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    y = m(x)[0]
+    y.float().square().mean().backward()
+    assert x.grad is not None and bool(torch.isfinite(x.grad.float()).all())
+    with pytest.raises(NotImplementedError):
+        m(torch.randn(1, 128, 128, device=DEV, dtype=torch.bfloat16))
