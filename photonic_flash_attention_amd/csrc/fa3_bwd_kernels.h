@@ -4,7 +4,8 @@
 // tests/unit/test_flash_attention_3.py:137-160 only require that gradients exist).  Here it is three kernels
 // that recompute P = exp(scale*S - LSE) tile by tile instead of storing the S x S matrices:
 //
-//   fa3_bwd_delta   delta[b,h,i] = sum_d dO[i,d] * O[i,d]                       (memory bound)
+//   fa3_bwd_delta   delta[b,h,i] = sum_d dO[i,d] * O[i,d]                       (memory bound; since the end of round 1 the
+//                   dQ kernel computes it for its own rows and publishes it for the dK/dV kernel -- this one is not launched)
 //   fa3_bwd_dq      per 256-row Q block (8 waves x 32 rows, same geometry / LDS images / DMA as the forward):
 //                     S^T = K Q^T, dP^T = V dO^T, dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T
 //   fa3_bwd_dkdv    per 128-key block (4 waves x 32 keys, one wave per SIMD: K^T/V^T operand fragments and the
@@ -273,7 +274,20 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
     const uint8_t* mrow = KMASK ? p.mask + (int64_t)b * p.m_sb + (int64_t)hh * p.m_sh + (int64_t)qrow * p.m_sq : nullptr;
     const int64_t stat = ((int64_t)b * p.H + hh) * p.Sq + qrow;
     const float lse = p.lse[stat];
-    const float delta = p.delta[stat];
+    // delta = rowsum(dO o O) of this lane's row, computed here (this kernel holds the dO row anyway; the lane pair (l, l^32)
+    // splits the row) and published for the dK/dV kernel that runs after it: no separate memory-bound delta pass
+    float delta = 0.f;
+    {
+        const T* op = (const T*)p.o + (int64_t)b * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)qrow * p.o_ss + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const v8 of = *(const v8*)(op + 16 * ks);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) delta += (float)of[e] * (float)gf[ks][e];
+        }
+        delta = row_pair_sum(delta);
+        if (h == 0 && my_q < p.Sq) p.delta[stat] = delta;
+    }
     const bool dead = !(lse > -INFINITY) || my_q >= p.Sq;
     const float lse2 = dead ? INFINITY : lse * 1.4426950408889634f;   // dead rows: exp2(x - inf) = 0 without a select
     const float c = p.scale_log2;

@@ -102,12 +102,12 @@ int pfa_fa3_bwd(const pfa_fa3_bwd_args* a, void* stream) {
     const int BH = a->B * a->H;
     void* args[] = {&p};
     const int rows_per_block = 256 / (a->D / 8);
-    p.nblk = 0;
-    e = hipLaunchKernel(kdelta, dim3((a->Sq + rows_per_block - 1) / rows_per_block, BH), dim3(256), args, 0, (hipStream_t)stream);
-    if (e == hipSuccess) {
-        p.nblk = (a->Sq + 255) / 256;
-        e = hipLaunchKernel(kdq, dim3((unsigned)(p.nblk * BH)), dim3(512), args, (size_t)lds, (hipStream_t)stream);
-    }
+    // (the dQ kernel computes delta = rowsum(dO o O) for its own rows and publishes it for the dK/dV kernel behind it;
+    //  fa3_bwd_delta_kernel is kept for reference / diagnostics but is no longer launched)
+    (void)kdelta;
+    (void)rows_per_block;
+    p.nblk = (a->Sq + 255) / 256;
+    e = hipLaunchKernel(kdq, dim3((unsigned)(p.nblk * BH)), dim3(512), args, (size_t)lds, (hipStream_t)stream);
     if (e == hipSuccess) {
         p.nblk = (a->Sk + 127) / 128;
         if (lds + 1024 > 64 * 1024)   // tile stages + the per-row constants exceed the default 64 KiB dynamic-LDS limit
