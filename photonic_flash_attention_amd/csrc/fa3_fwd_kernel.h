@@ -57,6 +57,7 @@ struct FwdParams {
     int32_t B, H, Sq, Sk;
     int32_t nqblk;        // ceil(Sq / BLOCK_M)
     int32_t kv_group;     // query heads per K/V head (>= 1): query head h reads K/V head h / kv_group
+    int32_t xcd_group;    // 4-wave kernel: walk the heads of an XCD in groups of this many (0 = all of them side by side)
     float scale_log2;     // softmax_scale * log2(e)
     unsigned long long* dbg;   // VAR_STAMP only: [workgroup][wave][8] cycle sums
 };

@@ -89,7 +89,18 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int BH = p.B * p.H, n = blockIdx.x, qrank = n / BH, bh = n - qrank * BH;
+    const int BH = p.B * p.H, n = blockIdx.x;
+    int qrank = n / BH, bh = n - qrank * BH;
+    // Workgroups n, n + 8, ... share an XCD (round-robin dispatch).  Default order: all heads of the XCD side by side, Q
+    // blocks heaviest first.  xcd_group = G > 0: the XCD walks its heads in groups of G (all Q blocks of a group before the
+    // next group), so that the ~32 resident workgroups stream G heads' K/V and every tile is fetched into that XCD's L2
+    // once and re-read there by the head's other Q blocks (FETCH_SIZE at C3: 225 MB -> 131 MB with G = 2).
+    if (p.xcd_group > 0 && (BH % 8) == 0 && ((BH / 8) % p.xcd_group) == 0) {
+        const int G = p.xcd_group, xcd = n & 7, idx = n >> 3, per_group = p.nqblk * G;
+        const int g = idx / per_group, within = idx - g * per_group;
+        qrank = within / G;
+        bh = xcd + 8 * (g * G + (within - qrank * G));
+    }
     const int qblk = CAUSAL ? (p.nqblk - 1 - qrank) : qrank;
     const int b = bh / p.H, hh = bh - b * p.H;
     const int q0 = qblk * BLOCK_M, wave_q0 = q0 + wave * 64;

@@ -25,6 +25,7 @@ struct Variant {
     int lds_bytes;
     int nthreads;
     int block_m;
+    int xcd_group = 0;
 };
 
 template <typename T, int D, bool C, bool S, bool K, int VAR, typename OT>
@@ -81,6 +82,10 @@ Variant w4_variant(const pfa_fa3_args* a, bool causal, bool out32) {
     v.lds_bytes = 4 * pfa::BLOCK_N * 128 * 2;
     v.nthreads = 256;
     v.block_m = 256;
+    // block order: an XCD walks its heads in groups of 4 (2 if 4 does not divide them): fewer heads' K/V live in its 4-MiB L2
+    // at a time -- FETCH_SIZE -30 % at C3, S = 2048 x 256 heads +5 %, C3 +1 %, C4 / C5 unchanged (variant 49: the old order)
+    const int hpx = (a->B * a->H) % 8 == 0 ? (a->B * a->H) / 8 : 0;
+    v.xcd_group = (hpx > 0 && hpx % 4 == 0) ? 4 : ((hpx > 0 && hpx % 2 == 0) ? 2 : 0);
     return v;
 }
 
@@ -95,6 +100,11 @@ Variant pick(const pfa_fa3_args* a) {
     // Variant 43 forces it, 44 forces the 8-wave kernel (A/B).
     const bool w4_ok = a->D == 128 && !split && !kmask;
     const int64_t avg_tiles = (causal ? (int64_t)a->Sk / 2 : (int64_t)a->Sk) / pfa::BLOCK_N;
+    if (w4_ok && (var == 47 || var == 48 || var == 49)) {      // A/B: head-grouped block order 2 / 4 / off
+        Variant v = w4_variant(a, causal, out32);
+        v.xcd_group = var == 47 ? 2 : (var == 48 ? 4 : 0);
+        return v;
+    }
     if (w4_ok && (var == 43 || (var == 0 && avg_tiles >= 32))) return w4_variant(a, causal, out32);
     if (var != 0 && var != 44 && a->dtype_in == PFA_DTYPE_BF16 && a->D == 128 && !split && !kmask && !out32) {
         switch (var) {
@@ -270,6 +280,7 @@ int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream) {
     const Variant v = pick(a);
     p.nqblk = (a->Sq + v.block_m - 1) / v.block_m;
     p.kv_group = a->kv_group > 1 ? a->kv_group : 1;
+    p.xcd_group = v.xcd_group;
     p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
 
     const unsigned grid = (unsigned)(p.nqblk * a->B * a->H);
