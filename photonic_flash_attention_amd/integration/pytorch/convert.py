@@ -118,8 +118,8 @@ def convert_to_photonic(model, dtype: Optional[torch.dtype] = None, inplace: boo
             why = "kdim/vdim differ from embed_dim"
         elif mha.bias_k is not None or mha.bias_v is not None or mha.add_zero_attn:
             why = "add_bias_kv / add_zero_attn"
-        elif mha.head_dim not in (64, 128):
-            why = f"head_dim {mha.head_dim} has no kernel (64, 128)"
+        elif mha.head_dim > 128:
+            why = f"head_dim {mha.head_dim} has no kernel (<= 128)"
         if why:
             report.skipped_layers.append(path)
             report.compatibility_warnings.append(f"{path or '<root>'}: {why}")

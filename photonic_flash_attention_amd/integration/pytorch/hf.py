@@ -49,8 +49,8 @@ def pfa_attention_forward(module, query, key, value, attention_mask, dropout: fl
         groups = query.shape[1] // key.shape[1]
         key = key.repeat_interleave(groups, dim=1)
         value = value.repeat_interleave(groups, dim=1)
-    if query.shape[-1] not in (64, 128):
-        raise NotImplementedError(f"head_dim {query.shape[-1]} has no kernel (64, 128)")
+    if query.shape[-1] > 128:
+        raise NotImplementedError(f"head_dim {query.shape[-1]} has no kernel (<= 128)")
     q_len = query.shape[2]
     causal = is_causal if is_causal is not None else getattr(module, "is_causal", True)
     causal = bool(q_len > 1 and attention_mask is None and causal)

@@ -23,7 +23,25 @@ from . import _capi
 
 _DT = {torch.bfloat16: _capi.PFA_DTYPE_BF16, torch.float16: _capi.PFA_DTYPE_FP16, torch.float32: _capi.PFA_DTYPE_FP32}
 
-SUPPORTED_HEAD_DIMS = (64, 128)
+SUPPORTED_HEAD_DIMS = (64, 128)      # kernel instantiations; other head dims <= 128 run zero-padded to the next one
+
+
+def _padded_head_dim(D: int) -> int:
+    """Kernel head dim for a problem of head dim ``D`` (``D`` itself when a kernel exists for it)."""
+    if D in SUPPORTED_HEAD_DIMS:
+        return D
+    if 1 <= D < SUPPORTED_HEAD_DIMS[-1]:
+        return next(d for d in SUPPORTED_HEAD_DIMS if d > D)
+    raise ValueError(f"head_dim {D} has no kernel (<= {SUPPORTED_HEAD_DIMS[-1]} supported)")
+
+
+def _pad_d(t: torch.Tensor, Dp: int) -> torch.Tensor:
+    """``[B,H,S,D]`` -> zero-padded ``[B,H,S,Dp]`` view of a fresh ``[B,S,H,Dp]`` buffer (zero q/k columns add nothing to the
+    scores, zero v columns give zero output columns)."""
+    B, H, S, D = t.shape
+    buf = torch.zeros((B, S, H, Dp), dtype=t.dtype, device=t.device)
+    buf[..., :D] = t.permute(0, 2, 1, 3)
+    return buf.permute(0, 2, 1, 3)
 
 
 def is_available(device: Optional[torch.device] = None) -> bool:
@@ -144,6 +162,20 @@ def fa3_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: bo
     fp32 reference ("numerics").
     """
     B, H, Sq, D = q.shape
+    Dp = _padded_head_dim(D)
+    if Dp != D:
+        # no kernel instantiation for this head dim: run the next larger one on zero-padded operands (same scores, the
+        # extra output columns are zero and dropped).  The scale stays the TRUE head dim's.
+        res = fa3_forward(_pad_d(q, Dp), _pad_d(k, Dp), _pad_d(v, Dp), causal=causal, seqlens_k=seqlens_k,
+                          key_mask=key_mask, mask=mask,
+                          softmax_scale=float(D ** -0.5 if softmax_scale is None else softmax_scale), out_dtype=out_dtype,
+                          return_lse=return_lse, return_weights=return_weights, weights_dtype=weights_dtype,
+                          split_p=split_p, _variant=_variant)
+        o = res[0][..., :D]
+        if out is not None:
+            out.copy_(o)
+            o = out
+        return (o,) + tuple(res[1:])
     if _variant is None:   # development only: experimental kernel variant (include/pfa_hip.h PFA_FLAG_VARIANT_MASK)
         _variant = int(os.environ.get("PFA_VARIANT", "0"))
     odt = q.dtype if out_dtype is None else out_dtype
@@ -195,6 +227,13 @@ def fa3_backward(q, k, v, out, dout, lse, *, causal: bool = False, seqlens_k=Non
     if k.shape[1] != H or v.shape[1] != H:
         raise ValueError("pfa_fa3_bwd wants one K/V head per query head: expand grouped K/V (repeat_interleave) before the "
                          "forward when gradients are needed; autograd then sums dK/dV over each group")
+    Dp = _padded_head_dim(D)
+    if Dp != D:   # as in fa3_forward: zero-padded head dim; the gradients' extra columns are exactly zero and dropped
+        grads = fa3_backward(_pad_d(q, Dp), _pad_d(k, Dp), _pad_d(v, Dp), _pad_d(out, Dp), _pad_d(dout, Dp), lse,
+                             causal=causal, seqlens_k=seqlens_k, key_mask=key_mask, mask=mask,
+                             softmax_scale=float(D ** -0.5 if softmax_scale is None else softmax_scale),
+                             grad_dtype=grad_dtype)
+        return tuple(g[..., :D] for g in grads)
     gdt = q.dtype if grad_dtype is None else grad_dtype
     if dout.stride(3) != 1:
         dout = dout.contiguous()

@@ -24,6 +24,9 @@ CASES = [
     (1, 2, 300, 300, 128, False, [257]),
     (1, 4, 1024, 1024, 128, True, None),
     (2, 1, 97, 513, 64, True, [513, 40]),
+    # head dims without a kernel instantiation run zero-padded to 64 / 128 (ops._padded_head_dim)
+    (1, 2, 130, 200, 32, True, None),
+    (2, 2, 256, 256, 96, False, [256, 77]),
 ]
 
 

@@ -101,7 +101,8 @@ def test_module_forward_matches_reference_module_golden():
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("cfg", [(2, 128, 512, 8), (4, 256, 768, 12), (1, 512, 1024, 16), (2, 96, 384, 6)])
+@pytest.mark.parametrize("cfg", [(2, 128, 512, 8), (4, 256, 768, 12), (1, 512, 1024, 16), (2, 96, 384, 6),
+                                 (2, 160, 256, 8), (1, 640, 384, 4)])      # head dims 32 and 96: zero-padded kernels
 def test_module_contract_like_reference_unit_tests(cfg, dtype):
     from photonic_flash_attention_amd import FlashAttention3
     orc = _oracle()

@@ -175,9 +175,9 @@ def test_scaled_inputs_stay_finite():
 def test_bad_arguments_raise_before_launch():
     from photonic_flash_attention_amd import ops
     dev = _dev()
-    q = torch.zeros(1, 2, 16, 80, dtype=torch.bfloat16, device=dev)
+    q = torch.zeros(1, 2, 16, 160, dtype=torch.bfloat16, device=dev)
     with pytest.raises(ValueError):
-        ops.fa3_forward(q, q, q)                      # head dim 80
+        ops.fa3_forward(q, q, q)                      # head dim 160 (> 128: no kernel; <= 128 runs zero-padded)
     q32 = torch.zeros(1, 2, 16, 64, dtype=torch.float32, device=dev)
     with pytest.raises(ValueError):
         ops.fa3_forward(q32, q32, q32)                # fp32 inputs
@@ -347,3 +347,30 @@ def test_grouped_query_heads_read_in_place(case):
         assert torch.equal(w_g, w_e)
     with pytest.raises(ValueError):
         ops.fa3_backward(q, k, v, o_g, o_g, l_g, causal=causal)
+
+
+@pytest.mark.parametrize("D", [8, 32, 40, 80, 96, 120])
+@pytest.mark.parametrize("causal", [False, True])
+def test_head_dims_without_a_kernel_run_zero_padded(D, causal):
+    """The reference takes any head dim (E // H); kernels exist for 64 and 128, smaller ones run zero-padded to the next
+    (same scores with the TRUE D^-0.5 scale, extra output columns dropped).  Tolerance 1e-3 on the parity variant."""
+    from oracle import fa3_oracle as orc
+    from photonic_flash_attention_amd import ops
+    from photonic_flash_attention_amd import synth
+    B, H, Sq, Sk = 2, 3, 150, 333
+    q, k, v = synth.qkv(B, H, Sq, Sk, D, 4000 + D, "bf16")
+    ref = orc.attention_bshd(q.float(), k.float(), v.float(), causal=causal)
+    DEV = _dev()
+    qd, kd, vd = (t.to(DEV).permute(0, 2, 1, 3) for t in (q, k, v))
+    out, lse, w = ops.fa3_forward(qd, kd, vd, causal=causal, out_dtype=torch.float32, return_lse=True, return_weights=True,
+                                  weights_dtype=torch.float32)
+    assert out.shape == (B, H, Sq, D) and w.shape == (B, H, Sq, Sk)
+    err = float((out.permute(0, 2, 1, 3).cpu() - ref).abs().max())
+    assert err <= 1e-3, f"D={D} causal={causal}: {err:.3e}"
+    assert float((w.sum(-1) - 1).abs().max()) <= 1e-3
+    given = torch.empty(B, Sq, H, D, device=DEV, dtype=torch.bfloat16).permute(0, 2, 1, 3)
+    o2 = ops.fa3_forward(qd, kd, vd, causal=causal, out=given)[0]
+    assert o2.data_ptr() == given.data_ptr()
+    assert float((o2.permute(0, 2, 1, 3).float().cpu() - ref).abs().max()) <= 2e-2     # bf16 store
+    with pytest.raises(ValueError):
+        ops.fa3_forward(*(torch.zeros(1, 1, 64, 256, device=DEV, dtype=torch.bfloat16) for _ in range(3)))
