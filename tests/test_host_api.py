@@ -256,7 +256,7 @@ def test_convert_to_photonic_replaces_torch_mha(monkeypatch):
             keep = ~pad if "src_key_padding_mask" in kw else torch.ones(2, 50, dtype=torch.bool)
             assert float((got - want)[keep].abs().max()) <= 2e-5, kw
     # skipped layers are reported, strings are refused
-    odd = nn.MultiheadAttention(96, 4)                               # head_dim 24: no kernel
+    odd = nn.MultiheadAttention(768, 4)                              # head_dim 192 > 128: no kernel
     _, rep2 = convert_to_photonic(nn.Sequential(odd))
     assert rep2.skipped_layers == ["0"] and "head_dim" in rep2.compatibility_warnings[0]
     with pytest.raises(ValueError):
