@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Fixed cost per workgroup: time the forward at Sq = 256 (one Q block per head, 1024 heads = 4 workgroups per CU) against the
+number of key tiles; the intercept of the line is what a workgroup pays outside its tile loop (Q load, first DMA, epilogue)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from photonic_flash_attention_amd import ops
+dev = torch.device("cuda:0")
+B, H, Sq, D = 64, 16, 256, int(os.environ.get("D", "128"))
+variant = int(os.environ.get("PFA_VARIANT", "0"))
+rows = []
+for Sk in (64, 128, 256, 512, 1024, 2048):
+    q = torch.randn(B, Sq, H, D, device=dev).to(torch.bfloat16).permute(0, 2, 1, 3)
+    k, v = (torch.randn(B, Sk, H, D, device=dev).to(torch.bfloat16).permute(0, 2, 1, 3) for _ in range(2))
+    out = torch.empty(B, Sq, H, D, device=dev, dtype=torch.bfloat16).permute(0, 2, 1, 3)
+    for _ in range(200):
+        ops.fa3_forward(q, k, v, out=out, _variant=variant)
+    best = []
+    for _ in range(7):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            ops.fa3_forward(q, k, v, out=out, _variant=variant)
+        e1.record(); torch.cuda.synchronize()
+        best.append(e0.elapsed_time(e1) / 50 * 1e3)
+    us = sorted(best)[len(best) // 2]
+    tiles = Sk // 64
+    rows.append((tiles, us))
+    print(f"Sk {Sk:5d} tiles {tiles:3d}: {us:8.1f} us  ({us / 4:6.2f} us per workgroup round, {4 * B * H * Sq * Sk * D / us / 1e6:7.1f} TF)")
+(t0, u0), (t1, u1) = rows[-2], rows[-1]
+slope = (u1 - u0) / (t1 - t0)
+print(f"slope {slope / 4:.3f} us per tile per workgroup; intercept {(u1 - slope * t1) / 4:.2f} us per workgroup")
