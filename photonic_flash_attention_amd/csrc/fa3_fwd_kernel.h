@@ -58,6 +58,7 @@ struct FwdParams {
     int32_t nqblk;        // ceil(Sq / BLOCK_M)
     int32_t kv_group;     // query heads per K/V head (>= 1): query head h reads K/V head h / kv_group
     int32_t xcd_group;    // 4-wave kernel: walk the heads of an XCD in groups of this many (0 = all of them side by side)
+    uint32_t magic_h, magic_g;   // 4-wave kernel: floor(2^32 / H) + 1 and floor(2^32 / kv_group) + 1 -- n / d == mulhi(n, magic) while n * d < 2^32
     float scale_log2;     // softmax_scale * log2(e)
     unsigned long long* dbg;   // VAR_STAMP only: [workgroup][wave][8] cycle sums
 };

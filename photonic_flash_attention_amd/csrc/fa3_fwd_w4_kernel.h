@@ -79,30 +79,38 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
     using v4 = typename E::v4;
     typedef __attribute__((address_space(3))) v8 lds_v8;
     constexpr int D = 128, NW = 4, BLOCK_M = 256, KS = D / 16, DB = D / 32;
+#ifdef PFA_W4_STAMP
+    const unsigned long long t_entry = stamp();
+    const unsigned long long rt_entry = __builtin_amdgcn_s_memrealtime();     // constant 100 MHz: absolute, comparable across CUs
+#endif
     constexpr int TILE_BYTES = BLOCK_N * D * 2, HALF_TILE = TILE_BYTES / 2;
     constexpr int K_BASE = 0, V_BASE = 2 * TILE_BYTES;
+    constexpr int Q_BASE = 4 * TILE_BYTES;                 // 64 KiB: the Q block's landing zone, [wave][strip][32 rows][256 B]
     constexpr int PPW = (TILE_BYTES / 1024) / NW;          // 4 DMA pieces per wave per image
     constexpr int PFK = 4, PFV = 3;                        // operand-fragment rings (steps ahead)
 
+    // Fetch every kernel argument the fill needs in ONE batch of scalar loads: left alone, hipcc loads them where they are first
+    // used -- ten dependent s_load / s_waitcnt round trips (~1500 cycles) before the first DMA piece could be issued.
+    asm volatile("" ::"s"(p.q), "s"(p.k), "s"(p.v), "s"(p.seqlens_k), "s"(p.q_sb), "s"(p.q_sh), "s"(p.q_ss), "s"(p.k_sb), "s"(p.k_sh),
+                 "s"(p.k_ss), "s"(p.v_sb), "s"(p.v_sh), "s"(p.v_ss), "s"(p.B), "s"(p.H), "s"(p.Sq), "s"(p.Sk), "s"(p.nqblk), "s"(p.kv_group),
+                 "s"(p.xcd_group), "s"(p.magic_h), "s"(p.magic_g), "s"(p.scale_log2));
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const uint32_t smem_base = (uint32_t)(uintptr_t)(lds_char*)smem;
 
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int BH = p.B * p.H, n = blockIdx.x;
-    int qrank = n / BH, bh = n - qrank * BH;
-    // Workgroups n, n + 8, ... share an XCD (round-robin dispatch).  Default order: all heads of the XCD side by side, Q
-    // blocks heaviest first.  xcd_group = G > 0: the XCD walks its heads in groups of G (all Q blocks of a group before the
-    // next group), so that the ~32 resident workgroups stream G heads' K/V and every tile is fetched into that XCD's L2
-    // once and re-read there by the head's other Q blocks (FETCH_SIZE at C3: 225 MB -> 131 MB with G = 2).
-    if (p.xcd_group > 0 && (BH % 8) == 0 && ((BH / 8) % p.xcd_group) == 0) {
-        const int G = p.xcd_group, xcd = n & 7, idx = n >> 3, per_group = p.nqblk * G;
-        const int g = idx / per_group, within = idx - g * per_group;
-        qrank = within / G;
-        bh = xcd + 8 * (g * G + (within - qrank * G));
-    }
+    // Launch geometry (pfa_capi.hip): x = XCD + 8 * (head within the XCD's current group of G heads), y = Q block rank,
+    // z = group.  Workgroups are dispatched x-fastest and workgroup n lands on XCD n % 8, so an XCD walks its heads G at a
+    // time -- all Q blocks of a group, heaviest first, before the next group: the ~32 resident workgroups stream G heads'
+    // K/V and a tile fetched into that XCD's L2 is re-read there by the head's other Q blocks (FETCH_SIZE at C3: 215 MB ->
+    // 161 MB with G = 4).  xcd_group = 0: x = head, y = Q block rank.  No integer divisions on the way to the first load.
+    const int qrank = blockIdx.y;
+    const int bh = p.xcd_group > 0 ? (int)(blockIdx.x & 7) + 8 * ((int)blockIdx.z * p.xcd_group + (int)(blockIdx.x >> 3)) : (int)blockIdx.x;
     const int qblk = CAUSAL ? (p.nqblk - 1 - qrank) : qrank;
-    const int b = bh / p.H, hh = bh - b * p.H;
+    // bh / H and hh / kv_group as multiply-high by floor(2^32 / d) + 1 (exact while n * d < 2^32: the host checks B * H * H;
+    // d = 1 has no such constant)
+    const int b = p.H == 1 ? bh : (int)__umulhi((uint32_t)bh, p.magic_h), hh = bh - b * p.H;
+    const int hkv = p.kv_group == 1 ? hh : (int)__umulhi((uint32_t)hh, p.magic_g);
     const int q0 = qblk * BLOCK_M, wave_q0 = q0 + wave * 64;
 
     int kv_len = p.Sk;
@@ -113,8 +121,8 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
     const int wnt = (wave_kv_end + BLOCK_N - 1) / BLOCK_N;                             // tiles this wave computes
 
     const T* qp = (const T*)p.q + (int64_t)b * p.q_sb + (int64_t)hh * p.q_sh;
-    const char* kp = (const char*)((const T*)p.k + (int64_t)b * p.k_sb + (int64_t)(hh / p.kv_group) * p.k_sh);
-    const char* vp = (const char*)((const T*)p.v + (int64_t)b * p.v_sb + (int64_t)(hh / p.kv_group) * p.v_sh);
+    const char* kp = (const char*)((const T*)p.k + (int64_t)b * p.k_sb + (int64_t)hkv * p.k_sh);
+    const char* vp = (const char*)((const T*)p.v + (int64_t)b * p.v_sb + (int64_t)hkv * p.v_sh);
 
     // ---- query-block state -----------------------------------------------------------------------------------------
     struct QB {
@@ -128,16 +136,7 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
     const float c = p.scale_log2;
     const float thr = 8.0f / c;
     auto init_qb = [&](QB& X, int first) {
-        X.my_q = first + r;
-        const T* src = qp + (int64_t)min(X.my_q, p.Sq - 1) * p.q_ss + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) X.qf[ks] = *(const v8*)(src + 16 * ks);
-#pragma unroll
-        for (int i = 0; i < DB; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) X.o[i][e] = 0.f;
-            asm volatile("" : "+a"(X.o[i]));
-        }
+        X.my_q = first + r;                 // O is zeroed beside the Q DMA (dma_q), in the shadow of its issue stalls
         X.m = -1e30f;
         X.l = 0.f;
         X.mc = -1e30f * c;
@@ -191,6 +190,30 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
     };
     auto dma_v = [&](int j, int t) {
         dma_piece(vsrd, voffd_t[t] + (uint32_t)j * v_tile, smem_base + V_BASE + (j & 1) * TILE_BYTES + (wave + NW * t) * 1024);
+    };
+    // Q takes the same road: per-lane 16-byte loads with a lane per ROW touch 32 cache lines per instruction and kept the
+    // four waves' address units busy for ~5000 cycles of every workgroup's fill; 1-KiB DMA pieces cover four WHOLE rows each.
+    // A wave fetches its own two strips into its own 16 KiB (chunk index XOR row, as in the store epilogue) and reads the
+    // fragments back after its own vmcnt wait -- no barrier.  Rows past Sq re-read row Sq - 1 (never stored).
+    const srd_t qsrd = whole_srd((const char*)qp, (uint32_t)(((int64_t)(p.Sq - 1) * p.q_ss + D) * 2));
+    auto dma_q = [&](QB& X, int blk) {
+        const int first = X.my_q - r;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int row = 4 * t + (lane >> 4);
+            const uint32_t voff = (uint32_t)(min(first + row, p.Sq - 1) * (int)p.q_ss) * 2u + (uint32_t)(((lane & 15) ^ (row & 15)) << 4);
+            dma_piece(qsrd, voff, smem_base + Q_BASE + wave * 16384 + blk * 8192 + t * 1024);
+            if (t & 1) {                    // a quarter of O's zeros after every second piece
+#pragma unroll
+                for (int e = 0; e < 16; ++e) X.o[t >> 1][e] = 0.f;
+                asm volatile("" : "+a"(X.o[t >> 1]));
+            }
+        }
+    };
+    auto read_q = [&](QB& X, int blk) {
+        const uint32_t base = smem_base + Q_BASE + wave * 16384 + blk * 8192 + r * 256;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) X.qf[ks] = *(const lds_v8*)(uintptr_t)(base + (((2 * ks + h) ^ (r & 15)) << 4));
     };
 
     // ---- per-lane LDS read addresses (opaque: see VAR_DIET in fa3_fwd_kernel.h) ---------------------------------------------
@@ -380,7 +403,7 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
 
     // ---- iterations ---------------------------------------------------------------------------------------------------------
     // interleaved: tile j's finish + PV beside tile j+1's QK^T + start (no masks on tile j+1)
-    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
+    unsigned long long st_acc[24] = {}, st_last = 0;
     auto steady = [&](auto pc, int j, f32x16 (&ca)[2], f32x16 (&cb)[2], f32x16 (&na)[2], f32x16 (&nb)[2]) {
         constexpr int P = decltype(pc)::value;
         uint32_t pa[16], pb[16];
@@ -453,46 +476,88 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
     f32x16 S0a[2], S0b[2], S1a[2], S1b[2];      // S(j) of even / odd tiles
     // The fill of a workgroup is bandwidth bound (Q 64 KiB + three 16-KiB tiles at ~11 B/cycle/CU): wait only for what the
     // first QK^T needs (Q, K0) and let V0 and K1 land under QK^T(0) and the first softmax start.
+#ifdef PFA_W4_STAMP
+    st_acc[16] = stamp() - t_entry;                                       // setup done
+#endif
+    // Issue order = arrival order: strip A's Q rows, K0, strip B's Q rows.  About 44 KiB are in flight per CU at a time (the
+    // pieces' issue stalls behind that), so strip A's QK^T(0) and softmax start run while strip B's rows are still arriving.
+    dma_q(A, 0);
 #pragma unroll
     for (int t = 0; t < PPW; ++t) dma_k(0, t);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // Q rows (issued in init_qb) and this wave's K0 pieces
+    dma_q(Bq, 1);
+#ifdef PFA_W4_STAMP
+    st_acc[8] = stamp() - t_entry;                                        // setup + issue of the Q and K0 pieces
+#endif
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                      // strip A's rows and this wave's K0 pieces
+#ifdef PFA_W4_STAMP
+    st_acc[9] = stamp() - t_entry;                                        // ... + Q(A) / K0 arrival
+#endif
+    read_q(A, 0);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {           // Q into the accumulator file, once
-        asm volatile("" : "+a"(A.qf[ks]));
-        asm volatile("" : "+a"(Bq.qf[ks]));
-    }
-#pragma unroll
-    for (int t = 0; t < PPW; ++t) dma_v(0, t);
-#pragma unroll
-    for (int t = 0; t < PPW; ++t) dma_k(1, t);
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(A.qf[ks]));    // Q into the accumulator file, once
     __builtin_amdgcn_s_barrier();               // everyone's K0 pieces are in LDS
+#ifdef PFA_W4_STAMP
+    st_acc[10] = stamp() - t_entry;                                       // ... + barrier
+#endif
+    auto qk_one = [&](auto ic, QB& X, f32x16 (&s)[2]) {      // QK^T(0) of one strip: 16 MFMAs, K fragments from slot 0
+        constexpr int i = decltype(ic)::value, kb = i / KS, ks = i % KS;
+        if constexpr (ks == 0) M::s0(s[kb], kfr[i % PFK], X.qf[ks]);
+        else M::s(s[kb], kfr[i % PFK], X.qf[ks]);
+        if constexpr (i + PFK < 2 * KS) kfr[i % PFK] = k_read(0, i + PFK);
+    };
     if (wnt > 0) {
         qk_begin(0);
-        w4_for<32>([&](auto hc) { qk_half(hc, 0, S0a, S0b); });
+        w4_for<16>([&](auto ic) {               // V0 and K1 are issued in the MFMA shadows
+            constexpr int i = decltype(ic)::value;
+            qk_one(ic, A, S0a);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (i % 2 == 1) {
+                if constexpr (i < 8) dma_v(0, i / 2);
+                else dma_k(1, i / 2 - 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");              // last MFMA -> first VALU read of S
         if (needs_mask(0)) {
             asm volatile("" ::: "memory");
             apply_mask(A, S0a, 0);
+        }
+        w4_for<16>([&](auto hc) { sm1_one(A, decltype(hc)::value, S0a); });
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                      // strip B's rows (V0 and K1 were issued behind them)
+    read_q(Bq, 1);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+a"(Bq.qf[ks]));
+    if (wnt > 0) {
+        qk_begin(0);
+        w4_for<16>([&](auto ic) { qk_one(ic, Bq, S0b); });
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+        if (needs_mask(0)) {
+            asm volatile("" ::: "memory");
             apply_mask(Bq, S0b, 0);
         }
-        w4_for<32>([&](auto hc) { sm1_half(hc, S0a, S0b); });
+        w4_for<16>([&](auto hc) { sm1_one(Bq, decltype(hc)::value, S0b); });
         A.alpha = 1.0f;                          // O is still zero
         Bq.alpha = 1.0f;
         any_grow = 0;
     }
+#ifdef PFA_W4_STAMP
+    st_acc[11] = stamp() - t_entry;                                       // ... + QK^T(0) + first softmax start
+#endif
     publish();                                  // V0 and K1 landed; K slot 0 is free for K(2)
 
+#ifdef PFA_W4_STAMP
+    const unsigned long long t_loop0 = stamp();
+    st_acc[5] = t_loop0 - t_entry;
+#endif
     for (int j = 0; j < nt; j += 2) {
         iter(IC<0>{}, j, S0a, S0b, S1a, S1b);
         if (j + 1 < nt) iter(IC<1>{}, j + 1, S1a, S1b, S0a, S0b);
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                  // last MFMA -> epilogue reads of O
 #ifdef PFA_W4_STAMP
-    if (lane == 0 && p.dbg) {
-        unsigned long long* d = p.dbg + ((size_t)blockIdx.x * NW + wave) * 8;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) d[i] = st_acc[i];
-    }
+    const unsigned long long t_loop1 = stamp();
+    st_acc[6] = t_loop1 - t_loop0;
 #endif
 
     // ---- epilogue: normalise, 16-byte stores (cdna guide T21) ----------------------------------------------------------------------
@@ -500,6 +565,8 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
     auto store_qb = [&](QB& X, int blk) {
         const float l_tot = row_pair_sum(X.l);
         const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        const f32x2 inv2 = {inv, inv};
         if constexpr (sizeof(OT) == 2) {
             // 16-bit store through LDS (free after the loop's last barrier; every wave uses its own 16 KiB): a lane pair
             // first forms 16-byte chunks of its row (cdna guide T21), the block is written as a [32 rows][256 B] image
@@ -512,9 +579,11 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
                 for (int g = 0; g < 4; g += 2) {
                     v4 wa, wb;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        wa[e] = (T)(X.o[db][4 * g + e] * inv);
-                        wb[e] = (T)(X.o[db][4 * g + 4 + e] * inv);
+                    for (int e = 0; e < 4; e += 2) {     // v_pk_mul_f32: two products per instruction
+                        const f32x2 pa = f32x2{X.o[db][4 * g + e], X.o[db][4 * g + e + 1]} * inv2;
+                        const f32x2 pb = f32x2{X.o[db][4 * g + 4 + e], X.o[db][4 * g + 5 + e]} * inv2;
+                        wa[e] = (T)pa[0]; wa[e + 1] = (T)pa[1];
+                        wb[e] = (T)pb[0]; wb[e + 1] = (T)pb[1];
                     }
                     const u32x2 ua = __builtin_bit_cast(u32x2, wa), ub = __builtin_bit_cast(u32x2, wb);
                     auto r0 = __builtin_amdgcn_permlane32_swap(ua[0], ub[0], false, false);
@@ -550,6 +619,19 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
     };
     store_qb(A, 0);
     store_qb(Bq, 1);
+#ifdef PFA_W4_STAMP
+    st_acc[12] = stamp() - t_loop1;                                       // normalise + stage + store issue
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    st_acc[7] = stamp() - t_loop1;
+    st_acc[13] = rt_entry;
+    st_acc[14] = __builtin_amdgcn_s_memrealtime();
+    st_acc[15] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);   // HW_ID, XCC_ID
+    if (lane == 0 && p.dbg) {
+        unsigned long long* d = p.dbg + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * NW + wave) * 24;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) d[i] = st_acc[i];
+    }
+#endif
 }
 
 }  // namespace pfa

@@ -23,6 +23,7 @@ struct Variant {
     const void* fn;
     char name[96];
     int lds_bytes;
+    bool grid3 = false;    // 4-wave kernel: (head-in-XCD-group, Q block, group) arrive as blockIdx.x/y/z -- no divisions in its prologue
     int nthreads;
     int block_m;
     int xcd_group = 0;
@@ -79,7 +80,8 @@ Variant w4_variant(const pfa_fa3_args* a, bool causal, bool out32) {
     v.fn = pfa::w4_kernel(a->dtype_in == PFA_DTYPE_BF16 ? 0 : 1, causal, out32);
     snprintf(v.name, sizeof(v.name), "fa3_fwd_w4_%s_d128_%s_%s", a->dtype_in == PFA_DTYPE_BF16 ? "bf16" : "fp16",
              causal ? "causal" : "full", out32 ? "o32" : "o16");
-    v.lds_bytes = 4 * pfa::BLOCK_N * 128 * 2;
+    v.grid3 = true;
+    v.lds_bytes = 8 * pfa::BLOCK_N * 128 * 2;      // K ring 2 + V ring 2 tiles, then the Q block's 64-KiB landing zone
     v.nthreads = 256;
     v.block_m = 256;
     // block order: an XCD walks its heads in groups of 4 (2 if 4 does not divide them): fewer heads' K/V live in its 4-MiB L2
@@ -95,17 +97,17 @@ Variant pick(const pfa_fa3_args* a) {
     const bool out32 = a->dtype_out == PFA_DTYPE_FP32;
     const unsigned var = (a->flags >> 8) & 0xffu;   // 0 = production default
     // The 4-wave x 64-row kernel (D = 128, single P, no element mask) wins once a workgroup streams enough key tiles to
-    // amortise its software-pipeline fill and drain: from ~32 tiles per workgroup on (tools/ab_bench.py, one box, both
-    // kernels with the LDS-staged epilogue: C3 +1 %, C4 +2 %, S8Kc +3 %, C5 +5 %; S2Kc -3 %, S1K -4 %, S512 -5 %).
-    // Variant 43 forces it, 44 forces the 8-wave kernel (A/B).
-    const bool w4_ok = a->D == 128 && !split && !kmask;
+    // amortise its fill and drain (one workgroup per CU: nothing overlaps them): from ~16 tiles per workgroup on
+    // (tools/ab_bench.py, one box, against the 8-wave kernel: S1K +2.6 %, S2Kc +0.5 %, C3 +4 %, C4 / C5 / S8Kc +5 %, S2K +8 %;
+    // below: S512 +1 %, S1Kc -6 %, S512c -6 %, S256 -5 %).  Variant 43 forces it, 44 forces the 8-wave kernel (A/B).
+    const bool w4_ok = a->D == 128 && !split && !kmask && (int64_t)a->B * a->H * a->H < (1ll << 32);   // last: its multiply-high head index
     const int64_t avg_tiles = (causal ? (int64_t)a->Sk / 2 : (int64_t)a->Sk) / pfa::BLOCK_N;
     if (w4_ok && (var == 47 || var == 48 || var == 49)) {      // A/B: head-grouped block order 2 / 4 / off
         Variant v = w4_variant(a, causal, out32);
         v.xcd_group = var == 47 ? 2 : (var == 48 ? 4 : 0);
         return v;
     }
-    if (w4_ok && (var == 43 || (var == 0 && avg_tiles >= 32))) return w4_variant(a, causal, out32);
+    if (w4_ok && (var == 43 || (var == 0 && avg_tiles >= 16))) return w4_variant(a, causal, out32);
     if (var != 0 && var != 44 && a->dtype_in == PFA_DTYPE_BF16 && a->D == 128 && !split && !kmask && !out32) {
         switch (var) {
             case 1: return exp_variant<pfa::VAR_SCHED | pfa::VAR_GLDS | pfa::VAR_BUFDMA>(causal);          // exact lazy rescale (no defer-max)
@@ -187,6 +189,7 @@ int check(const pfa_fa3_args* a) {
     // K/V slabs of one (batch, head) are addressed through 32-bit buffer descriptors
     if (((int64_t)(a->Sk - 1) * a->k_stride_s + a->D) * 2 > 0x7fffffffLL) return PFA_ERR_SHAPE;
     if (((int64_t)(a->Sk - 1) * a->v_stride_s + a->D) * 2 > 0x7fffffffLL) return PFA_ERR_SHAPE;
+    if (((int64_t)(a->Sq - 1) * a->q_stride_s + a->D) * 2 > 0x7fffffffLL) return PFA_ERR_SHAPE;   // the 4-wave kernel's Q DMA
     if (a->k_stride_s < 0 || a->v_stride_s < 0 || a->k_stride_s * 64 > 0x3fffffffLL || a->v_stride_s * 64 > 0x3fffffffLL)
         return PFA_ERR_STRIDE;
     return PFA_OK;
@@ -282,8 +285,19 @@ int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream) {
     p.kv_group = a->kv_group > 1 ? a->kv_group : 1;
     p.xcd_group = v.xcd_group;
     p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
+    p.magic_h = (uint32_t)((1ull << 32) / (uint64_t)a->H) + 1u;
+    p.magic_g = (uint32_t)((1ull << 32) / (uint64_t)p.kv_group) + 1u;
 
-    const unsigned grid = (unsigned)(p.nqblk * a->B * a->H);
+    dim3 grid((unsigned)(p.nqblk * a->B * a->H));
+    if (v.grid3) {
+        // linear dispatch order is x fastest and workgroup n runs on XCD n % 8: x = XCD + 8 * (head within the XCD's current
+        // group of G), y = Q block rank (heaviest first), z = group  ==  the order the kernel used to derive with divisions
+        const int BH = a->B * a->H;
+        if (p.xcd_group > 0 && (BH % (8 * p.xcd_group) != 0 || BH / (8 * p.xcd_group) > 65535)) p.xcd_group = 0;
+        if (p.nqblk > 65535) return PFA_ERR_SHAPE;
+        grid = p.xcd_group > 0 ? dim3(8u * p.xcd_group, (unsigned)p.nqblk, (unsigned)(BH / (8 * p.xcd_group)))
+                               : dim3((unsigned)BH, (unsigned)p.nqblk, 1u);
+    }
     void* kargs[] = {&p};
     int prev_dev = -1;
     hipError_t e = hipGetDevice(&prev_dev);
@@ -295,7 +309,7 @@ int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream) {
     }
     if (v.lds_bytes > 64 * 1024)   // opt in to > 64 KiB of dynamic LDS (idempotent, per function)
         (void)hipFuncSetAttribute(v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds_bytes);
-    e = hipLaunchKernel(v.fn, dim3(grid), dim3(v.nthreads), kargs, (size_t)v.lds_bytes, (hipStream_t)stream);
+    e = hipLaunchKernel(v.fn, grid, dim3(v.nthreads), kargs, (size_t)v.lds_bytes, (hipStream_t)stream);
     if (prev_dev != a->device_id) (void)hipSetDevice(prev_dev);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;
