@@ -327,7 +327,9 @@ def test_speedup_over_the_eager_tiled_loop_on_this_gpu():
     assert t_eager / t_kernel >= 20
 
 
-@pytest.mark.parametrize("case", [(2, 8, 2, 300, 300, 64, True), (1, 8, 4, 512, 2048, 128, False), (1, 4, 1, 4096, 4096, 128, True)])
+@pytest.mark.parametrize("case", [(2, 8, 2, 300, 300, 64, True), (1, 8, 4, 512, 2048, 128, False), (1, 4, 1, 4096, 4096, 128, True),
+                                  # groups of 3 (the 4-wave kernel's multiply-high head index), and 32 heads x batches (its head-grouped order)
+                                  (1, 6, 2, 512, 1024, 128, False), (4, 8, 2, 512, 1024, 128, True)])
 def test_grouped_query_heads_read_in_place(case):
     """ABI v4 `kv_group`: K/V with H / g heads, query head h reading K/V head h // g, must equal the run on K/V expanded with
     repeat_interleave bit for bit (both forward kernels), also for the weights pass; the backward refuses grouped K/V."""
