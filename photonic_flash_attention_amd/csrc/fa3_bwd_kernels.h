@@ -204,7 +204,7 @@ __device__ __forceinline__ void store_tile_rows_via_lds(const f32x16 (&acc)[D / 
                                                         char* grow0, int64_t row_stride_bytes, int rows_valid) {
     using v4 = typename Elem<T>::v4;
     typedef __attribute__((address_space(3))) u32x4 lds_u32x4_t;
-    constexpr int RB = D * 2, CPRW = RB / 16, RPI = 64 / CPRW;
+    constexpr int RB = D * 2, CPRW = RB / 16;
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int db = 0; db < D / 32; ++db)
@@ -223,13 +223,7 @@ __device__ __forceinline__ void store_tile_rows_via_lds(const f32x16 (&acc)[D / 
             const uint32_t ch = 4 * db + g + h;
             *(lds_u32x4_t*)(uintptr_t)(lbase + r * RB + ((ch ^ (r & (CPRW - 1))) << 4)) = w;
         }
-    const int cc = lane & (CPRW - 1);
-#pragma unroll
-    for (int i = 0; i < 32 / RPI; ++i) {
-        const int row = RPI * i + lane / CPRW;
-        const u32x4 x = *(const lds_u32x4_t*)(uintptr_t)(lbase + row * RB + ((cc ^ (row & (CPRW - 1))) << 4));
-        if (row < rows_valid) *(u32x4*)(grow0 + (int64_t)row * row_stride_bytes + 16 * cc) = x;
-    }
+    store_rows_from_lds<RB>(lbase, lane, grow0, row_stride_bytes, rows_valid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

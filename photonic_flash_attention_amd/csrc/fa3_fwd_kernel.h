@@ -232,6 +232,34 @@ __device__ __forceinline__ unsigned long long stamp() {
 }
 typedef __amdgpu_buffer_rsrc_t srd_t;
 
+// Second half of the LDS-staged row store (every epilogue: forward O, backward dQ / dK / dV): read a [32 rows][RB bytes] image
+// (16-byte chunk index XOR row) back so that one store instruction covers 64 / CPRW WHOLE rows.  All reads are issued before the
+// first store: written as one loop, hipcc sinks each ds_read_b128 into its store's predicated block and the epilogue pays 8
+// serial LDS round trips (ds_read, s_waitcnt lgkmcnt(0), store, next ...).  rows_valid is wave-uniform.
+template <int RB>
+__device__ __forceinline__ void store_rows_from_lds(uint32_t lbase, int lane, char* grow0, int64_t row_stride_bytes, int rows_valid) {
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4_t;
+    constexpr int CPRW = RB / 16, RPI = 64 / CPRW, NI = 32 / RPI;      // chunks per row, rows per store instruction, instructions
+    const int cc = lane & (CPRW - 1), lr = lane / CPRW;
+    u32x4 x[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int row = RPI * i + lr;
+        x[i] = *(const lds_u32x4_t*)(uintptr_t)(lbase + row * RB + ((cc ^ (row & (CPRW - 1))) << 4));
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(x[i]));
+    char* g = grow0 + 16 * cc + (int64_t)lr * row_stride_bytes;
+    if (rows_valid >= 32) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) *(u32x4*)(g + (int64_t)(RPI * i) * row_stride_bytes) = x[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            if (RPI * i + lr < rows_valid) *(u32x4*)(g + (int64_t)(RPI * i) * row_stride_bytes) = x[i];
+    }
+}
+
 // LDS-DMA piece through a buffer descriptor: lane address = SRD base + voff, out-of-range lanes (rows past the
 // end of the K/V slab) deliver zeros, so ragged tails need no clamp.  s_nop 4: SGPR-written-by-SALU -> VMEM.
 __device__ __forceinline__ void lds_dma16_buf(srd_t srd, uint32_t voff, uint32_t lds_dst) {
@@ -820,7 +848,7 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
         // index XOR-swizzled by the row) and come back so that one store instruction covers WHOLE rows: per-lane stores
         // at the row stride touch 64 cache lines per instruction, these 8 (D = 128) or 16 (D = 64).
         typedef __attribute__((address_space(3))) u32x4 lds_u32x4_t;
-        constexpr int RB = D * 2, CPRW = RB / 16, RPI = 64 / CPRW;      // row bytes, chunks per row, rows per store instruction
+        constexpr int RB = D * 2, CPRW = RB / 16;      // row bytes, 16-byte chunks per row
         const uint32_t lbase = smem_base + wave * (32 * RB);
 #pragma unroll
         for (int db = 0; db < DB; ++db)
@@ -839,14 +867,8 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
                 const uint32_t ch = 4 * db + g + h;
                 *(lds_u32x4_t*)(uintptr_t)(lbase + r * RB + ((ch ^ (r & (CPRW - 1))) << 4)) = w;
             }
-        const int cc = lane & (CPRW - 1);
-        char* obase = (char*)((OT*)p.o + (int64_t)b * p.o_sb + (int64_t)hh * p.o_sh) + 16 * cc;
-#pragma unroll
-        for (int i = 0; i < 32 / RPI; ++i) {
-            const int row = RPI * i + lane / CPRW;
-            const u32x4 x = *(const lds_u32x4_t*)(uintptr_t)(lbase + row * RB + ((cc ^ (row & (CPRW - 1))) << 4));
-            if (wave_q0 + row < p.Sq) *(u32x4*)(obase + (int64_t)(wave_q0 + row) * p.o_ss * 2) = x;
-        }
+        store_rows_from_lds<RB>(lbase, lane, (char*)((OT*)p.o + (int64_t)b * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)wave_q0 * p.o_ss),
+                                p.o_ss * 2, p.Sq - wave_q0);
     } else if (my_q < p.Sq) {
         OT* orow = (OT*)p.o + (int64_t)b * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)my_q * p.o_ss;
 #pragma unroll

@@ -592,14 +592,9 @@ __global__ __launch_bounds__(256, 1) void fa3_fwd_w4_kernel(const FwdParams p) {
                     const uint32_t ch = 4 * db + g + h;                   // 16-byte chunk of the row this lane now holds
                     *(lds_u32x4*)(uintptr_t)(lbase + r * 256 + ((ch ^ (r & 15)) << 4)) = w;
                 }
-            const int first = X.my_q - r, cc = lane & 15;
-            char* obase = (char*)((OT*)p.o + (int64_t)b * p.o_sb + (int64_t)hh * p.o_sh) + 16 * cc;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = 4 * i + (lane >> 4);
-                const u32x4 x = *(const lds_u32x4*)(uintptr_t)(lbase + row * 256 + ((cc ^ (row & 15)) << 4));
-                if (first + row < p.Sq) *(u32x4*)(obase + (int64_t)(first + row) * p.o_ss * 2) = x;
-            }
+            const int first = __builtin_amdgcn_readfirstlane(X.my_q - r);
+            store_rows_from_lds<256>(lbase, lane, (char*)((OT*)p.o + (int64_t)b * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)first * p.o_ss),
+                                     p.o_ss * 2, p.Sq - first);
         } else if (X.my_q < p.Sq) {
             OT* orow = (OT*)p.o + (int64_t)b * p.o_sb + (int64_t)hh * p.o_sh + (int64_t)X.my_q * p.o_ss;
 #pragma unroll
