@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void fa3_weights_kernel(const WeightsParams p)
     // wave, 16-byte units XOR-swizzled by the row) and leaves as WHOLE 128- or 256-byte row segments, 8 or 4 rows per
     // store instruction -- the per-lane form below writes 8/16-byte pieces at the row stride (half a cache line per row
     // and key block) and ran at 1.2-2.4 TB/s.
-    constexpr int ES = sizeof(WT), CB = 4 * ES, RB = 64 * ES, NU = RB / 16, RPI = 64 / NU;
+    constexpr int ES = sizeof(WT), CB = 4 * ES, RB = 64 * ES, NU = RB / 16;
     __shared__ __attribute__((aligned(16))) char wbuf[4 * 32 * RB];
     typedef __attribute__((address_space(3))) char lchar;
     lchar* const lbase = (lchar*)wbuf + wave * (32 * RB);
@@ -121,13 +121,8 @@ __global__ __launch_bounds__(256) void fa3_weights_kernel(const WeightsParams p)
                     }
                 }
             }
-#pragma unroll
-            for (int i = 0; i < 32 / RPI; ++i) {
-                const int row = RPI * i + lane / NU, u = lane % NU;
-                const u32x4 x = *(const __attribute__((address_space(3))) u32x4*)(lbase + row * RB + ((u ^ (row & (NU - 1))) << 4));
-                if (wave_q0 + row < p.Sq)
-                    *(u32x4*)(wbase + ((int64_t)(wave_q0 + row) * p.w_sq + key_base) * ES + 16 * u) = x;
-            }
+            store_rows_from_lds<RB>((uint32_t)(uintptr_t)lbase, lane, wbase + ((int64_t)wave_q0 * p.w_sq + key_base) * ES, p.w_sq * ES,
+                                    p.Sq - wave_q0);
         }
     }
     // remaining key blocks (tails, unaligned rows): per-lane stores
