@@ -39,7 +39,7 @@ MFMA_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, 
 # per the gfx950 wide-load correction of MI355X_MICROARCH.md section HBM, + WRITE_SIZE).  Not measurable from inside
 # this process, so the committed profile is quoted, keyed by workload; null for anything not profiled.
 PMC_TRAFFIC_BYTES = {
-    "C3": (412.0e6, "profiles/r01_v8_C3_rocprof_summary.md: FETCH_SIZE 168405 KB x 2 + WRITE_SIZE 65536 KB"),
+    "C3": (392.6e6, "profiles/r01_v9_C3_rocprof_summary.md: FETCH_SIZE 158932 KB x 2 + WRITE_SIZE 65536 KB"),
 }
 
 WORKLOADS = {
