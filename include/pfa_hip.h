@@ -145,7 +145,7 @@ int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream);
  * returns un-renormalised tiles; documented divergence).  `a` is the argument block of the forward call that
  * produced a->lse (required; a->v and a->o are ignored).  W is addressed base + b*w_stride_b + h*w_stride_h +
  * i*w_stride_q + j (ELEMENT strides, last dim contiguous), dtype w_dtype = a->dtype_in or PFA_DTYPE_FP32.
- * For causal or seqlens_k problems the caller must zero-fill W first (fully masked 32-key blocks are skipped).
+ * Every element of W is written exactly once (masked ones as zeros): W may be uninitialised.
  */
 int pfa_fa3_weights(const pfa_fa3_args* a, void* w, int32_t w_dtype, int64_t w_stride_b, int64_t w_stride_h,
                     int64_t w_stride_q, void* stream);

@@ -9,7 +9,7 @@
 //
 // Workgroup = 128 query rows, 4 waves; a wave takes every fourth 64-key column block for all four 32-row strips, K fragments straight
 // from global/L2 to registers and shared by the four strips (no LDS for K).  Fully masked key blocks of a
-// causal problem are skipped: the host zero-fills W first.
+// causal problem are not computed: the kernel writes their zeros (every element of W is written exactly once).
 #pragma once
 #include "fa3_fwd_kernel.h"
 
@@ -117,13 +117,27 @@ __global__ __launch_bounds__(256) void fa3_weights_kernel(const WeightsParams p)
 #pragma unroll
         for (int s = 0; s < NS; ++s) load_strip(S[s], s);
         const int wg_kv_end = strip_kv_end(NS - 1);
-        for (int key_base = 64 * wave; key_base < fast_limit && key_base < wg_kv_end; key_base += 64 * 4) {
+        for (int key_base = 64 * wave; key_base < fast_limit; key_base += 64 * 4) {
             v8 kf[2][KS];
-            load_k(key_base, kf[0]);
-            load_k(key_base + 32, kf[1]);
+            if (key_base < wg_kv_end) {
+                load_k(key_base, kf[0]);
+                load_k(key_base + 32, kf[1]);
+            }
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                if (key_base >= strip_kv_end(s) || q0 + 32 * s >= p.Sq) continue;      // wave-uniform
+                if (q0 + 32 * s >= p.Sq) continue;                                      // wave-uniform
+                if (key_base >= strip_kv_end(s)) {
+                    // nothing of this block is visible to the strip (above the diagonal, past the batch's key length): the kernel
+                    // writes the zeros itself -- W is written exactly once, the caller allocates it uninitialised
+                    constexpr int RPI = 64 / NU, NI = 32 / RPI;
+                    const int lr = lane / NU, rows_valid = p.Sq - (q0 + 32 * s);
+                    char* g = (char*)(whead + (int64_t)(q0 + 32 * s + lr) * p.w_sq + key_base) + 16 * (lane & (NU - 1));
+                    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+                        if (RPI * i + lr < rows_valid) *(u32x4*)(g + (int64_t)(RPI * i) * p.w_sq * ES) = z;
+                    continue;
+                }
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
                     float w[16];
@@ -155,7 +169,9 @@ __global__ __launch_bounds__(256) void fa3_weights_kernel(const WeightsParams p)
     load_strip(S, wave);
     const int kv_end = strip_kv_end(wave);
     WT* __restrict__ wrow = whead + (int64_t)min(S.my_q, p.Sq - 1) * p.w_sq;
-    for (int key_base = min(fast_limit, ((kv_end + 63) / 64) * 64); key_base < kv_end; key_base += 32) {
+    // (runs to Sk, not to the strip's last visible key: masked elements come out of block_k as zeros and are written too)
+    (void)kv_end;
+    for (int key_base = fast_limit; key_base < p.Sk; key_base += 32) {
         v8 kf[KS];
         load_k(key_base, kf);
         float w[16];

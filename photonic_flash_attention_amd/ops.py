@@ -195,9 +195,7 @@ def fa3_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: bo
     if return_weights:
         Sk = k.shape[2]
         wdt = q.dtype if weights_dtype is None else weights_dtype
-        # causal / ragged problems skip fully masked key blocks, so those must read as zeros
-        alloc = torch.zeros if (causal or seqlens_k is not None) else torch.empty
-        weights = alloc((B, H, Sq, Sk), dtype=wdt, device=q.device)
+        weights = torch.empty((B, H, Sq, Sk), dtype=wdt, device=q.device)     # the kernel writes every element, masked ones as zeros
         stw = _capi.load().pfa_fa3_weights(C.byref(args), C.c_void_p(weights.data_ptr()), _DT[wdt],
                                            weights.stride(0), weights.stride(1), weights.stride(2), C.c_void_p(stream))
         if stw in (-3, -4, -5, -6, -7, -10):

@@ -278,3 +278,34 @@ def test_training_dropout_follows_the_reference_branch_rule():
     assert x.grad is not None and bool(torch.isfinite(x.grad.float()).all())
     with pytest.raises(NotImplementedError):
         m(torch.randn(1, 128, 128, device=DEV, dtype=torch.bfloat16))
+
+
+@pytest.mark.parametrize("case", [(2, 3, 200, 333, 64, True), (1, 2, 300, 1024, 128, True), (2, 2, 257, 640, 128, False),
+                                  (1, 4, 1024, 1024, 64, True)])
+def test_weights_pass_writes_every_element(case):
+    """`pfa_fa3_weights` takes an UNINITIALISED buffer: blocks above the causal diagonal / past a batch's key length are written as
+    zeros by the kernel itself (no caller zero-fill).  The allocator is poisoned with NaN first so that an element the kernel
+    skipped cannot pass by luck; Sk = 333 also takes the unaligned per-lane path."""
+    from photonic_flash_attention_amd import ops
+    orc = _oracle()
+    B, H, Sq, Sk, D, causal = case
+    q, k, v = synth.qkv(B, H, Sq, Sk, D, 7100 + Sq, "bf16")
+    lens = [Sk - 37 * b_ for b_ in range(B)]
+    qd, kd, vd = (t.to(DEV).permute(0, 2, 1, 3) for t in (q, k, v))
+    for wdt in (torch.float32, torch.bfloat16):
+        poison = torch.full((B, H, Sq, Sk), float("nan"), dtype=wdt, device=DEV)
+        del poison                       # the caching allocator hands the same block to the weights tensor below
+        w = ops.fa3_forward(qd, kd, vd, causal=causal, seqlens_k=lens, return_weights=True, weights_dtype=wdt)[2]
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(w.float()).all()), (case, wdt)
+        s = (q.float().permute(0, 2, 1, 3) @ k.float().permute(0, 2, 3, 1)) * D ** -0.5
+        keep = torch.ones(Sq, Sk, dtype=torch.bool)
+        if causal:
+            keep &= torch.ones(Sq, Sk, dtype=torch.bool).tril()
+        keep = keep[None, None].expand(B, H, Sq, Sk).clone()
+        for b_, n_ in enumerate(lens):
+            keep[b_, :, :, n_:] = False
+        ref = torch.nan_to_num(torch.softmax(s.masked_fill(~keep, float("-inf")), dim=-1), nan=0.0)
+        got = w.float().cpu()
+        assert float((got - ref).abs().max()) <= (2e-3 if wdt == torch.float32 else 6e-3), (case, wdt)
+        assert float(got[~keep].abs().max()) == 0.0
