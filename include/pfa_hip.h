@@ -130,9 +130,10 @@ int pfa_device_supported(int device_id);
 /* Last hipError_t seen by a failing call on this thread (0 = hipSuccess). */
 int pfa_last_hip_error(void);
 
-/* Scratch bytes pfa_fa3_fwd can use for `a`: 0 without a key mask; with one, 8 bytes per batch and 64-key tile -- pfa_fa3_fwd first
- * condenses the [B,Sk] mask into one 64-bit word per tile there (one word read per tile instead of a mask byte per score: 2-3 x
- * faster).  Optional: with workspace == NULL or too few bytes the mask is read byte-wise and the result is the same. */
+/* Scratch bytes pfa_fa3_fwd can use for `a`: 0 without a mask; with key_mask or mask, 8 bytes per un-broadcast mask row and
+ * 64-key tile -- pfa_fa3_fwd first condenses the mask into one 64-bit word per row and tile there (one word read per tile
+ * instead of a mask byte per score: 2-4 x faster).  Optional: with workspace == NULL or too few bytes the mask is read
+ * byte-wise and the result is the same. */
 size_t pfa_fa3_workspace_bytes(const pfa_fa3_args* a);
 
 /* Validate `a` without launching: PFA_OK or the error pfa_fa3_fwd would return. */

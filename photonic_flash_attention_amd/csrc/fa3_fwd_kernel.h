@@ -61,8 +61,11 @@ struct FwdParams {
     uint32_t magic_h, magic_g;   // 4-wave kernel: floor(2^32 / H) + 1 and floor(2^32 / kv_group) + 1 -- n / d == mulhi(n, magic) while n * d < 2^32
     float scale_log2;     // softmax_scale * log2(e)
     unsigned long long* dbg;   // VAR_STAMP only: [workgroup][wave][8] cycle sums
-    const unsigned long long* kbits;   // [B][kbits_nt]: bit i of word (b, j) = key 64 j + i of batch b is visible (fa3_keybits_kernel from the
-    int32_t kbits_nt;                  // [B,Sk] key mask); null: the mask is read a byte per score
+    // mask condensed to 64-bit words by fa3_maskbits_kernel: bit i of word (b, h, q, j) = key 64 j + i is visible to row q of head h
+    // of batch b; word address mbits + b*mb_sb + h*mb_sh + q*mb_sq + j (strides in words, 0 = broadcast: a [B,Sk] key mask has
+    // mb_sh = mb_sq = 0).  null: the mask is read a byte per score.
+    const unsigned long long* mbits;
+    int64_t mb_sb, mb_sh, mb_sq;
 };
 
 template <typename T> struct Elem;
@@ -288,17 +291,20 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, uint32_t lds_dst) {
         : "memory");
 }
 
-// [B,Sk] key mask (u8, 0 = masked) -> one 64-bit word per 64-key tile.  The forward then reads ONE word per tile: all ones = no
-// masking work, zero = the tile is skipped, anything else = bit tests -- where reading the mask itself cost 32 scattered byte
-// loads per lane and tile (2-3 x the run time of the unmasked problem).  Grid (ceil(nt / 4), B), 4 waves = 4 tiles per block.
+// u8 mask (0 = masked; byte strides, 0 = broadcast) -> one 64-bit word per mask row and 64-key tile.  The forward then reads
+// ONE word per row and tile: all ones = no masking work, all zero = the tile is skipped, anything else = bit tests -- where
+// reading the mask itself cost 32 scattered byte loads per lane and tile (2-6 x the run time of the unmasked problem).
+// One wave per word: grid (ceil(nt / 4), rows = Qm, Bm * Hm) with Bm / Hm / Qm = the mask's own (un-broadcast) extents.
 template <int UNUSED = 0>   // (a template only so that the three translation units including this header do not each define it)
-__global__ __launch_bounds__(256) void fa3_keybits_kernel(const uint8_t* km, int64_t stride_b, int Sk, int nt, unsigned long long* out) {
-    const int lane = threadIdx.x & 63, tile = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+__global__ __launch_bounds__(256) void fa3_maskbits_kernel(const uint8_t* m, int64_t sb, int64_t sh, int64_t sq, int64_t sk, int Hm, int Sk,
+                                                          int nt, unsigned long long* out, int64_t ob, int64_t oh, int64_t oq) {
+    const int lane = threadIdx.x & 63, tile = blockIdx.x * 4 + (threadIdx.x >> 6), q = blockIdx.y;
+    const int b = blockIdx.z / Hm, hh = blockIdx.z - b * Hm;
     if (tile >= nt) return;
     const int key = tile * 64 + lane;
-    const bool on = key < Sk && km[(int64_t)b * stride_b + key] != 0;
+    const bool on = key < Sk && m[(int64_t)b * sb + (int64_t)hh * sh + (int64_t)q * sq + (int64_t)key * sk] != 0;
     const unsigned long long bits = __builtin_amdgcn_ballot_w64(on);
-    if (lane == 0) out[(int64_t)b * nt + tile] = bits;
+    if (lane == 0) out[(int64_t)b * ob + (int64_t)hh * oh + (int64_t)q * oq + tile] = bits;
 }
 
 template <typename T, int D, bool CAUSAL, bool SPLITP, bool KMASK, int VAR, typename OT>
@@ -521,16 +527,27 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
 
     unsigned long long st_qk_end = 0;
     // ---- one K/V tile: S^T = K Q^T, online softmax, O^T += V^T P^T -------------------------------------------
-    unsigned long long tile_bits = ~0ull;      // KMASK + kbits: the current tile's key-mask word (set by tile_live)
+    // KMASK + mbits: the row's mask word of the current tile, fetched one tile ahead (consumed after the previous step's
+    // s_waitcnt vmcnt(0), so the wait hipcc puts in front of its use never holds up the K/V prefetch issued behind it)
+    unsigned long long tile_bits = ~0ull, next_bits = ~0ull;
+    bool tile_all_ones = true;
+    const unsigned long long* mrow = nullptr;
+    if constexpr (KMASK) {
+        if (p.mbits) mrow = p.mbits + (int64_t)b * p.mb_sb + (int64_t)hh * p.mb_sh + (int64_t)min(my_q, p.Sq - 1) * p.mb_sq;
+    }
+    auto fetch_bits = [&](int j) {
+        if constexpr (KMASK) {
+            if (mrow) next_bits = mrow[min(j, (p.Sk + BLOCK_N - 1) / BLOCK_N - 1)];
+        }
+    };
     auto tile_live = [&](int j) {              // does this wave compute tile j?  (wave-uniform)
         if (!(j * BLOCK_N < wave_kv_end)) return false;
         if constexpr (KMASK) {
-            if (p.kbits) {
-                const unsigned long long wbits = p.kbits[(int64_t)b * p.kbits_nt + j];
-                const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(wbits >> 32));   // (the builtin returns int:
-                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)wbits);           //  no sign extension)
-                tile_bits = ((unsigned long long)hi << 32) | lo;
-                return tile_bits != 0;             // no key of the tile is visible: skip it (m, l, O unchanged)
+            if (mrow) {
+                tile_bits = next_bits;
+                fetch_bits(j + 1);
+                tile_all_ones = __builtin_amdgcn_ballot_w64(tile_bits != ~0ull) == 0;
+                return __builtin_amdgcn_ballot_w64(tile_bits != 0ull) != 0;   // no key of the tile is visible to any row: skip it
             }
         }
         return true;
@@ -628,9 +645,9 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
             st_qk_end = tq1;
         }
         // mask: wave-uniform test, only diagonal / tail / key-mask tiles pay
-        const bool bits_mode = KMASK && p.kbits != nullptr;                      // key mask as one word per tile (tile_bits)
+        const bool bits_mode = KMASK && mrow != nullptr;                         // mask as one word per row and tile (tile_bits)
         const bool need_mask = (key_base + BLOCK_N > kv_len) || (CAUSAL && key_base + BLOCK_N - 1 > wave_q0) ||
-                               (KMASK && (!bits_mode || tile_bits != ~0ull));
+                               (KMASK && (!bits_mode || !tile_all_ones));
         if (need_mask) {
             asm volatile("" ::: "memory");   // keep this a real (wave-uniform) branch: hipcc otherwise if-converts
                                              // it into 32 v_cmp + 32 v_cndmask on EVERY tile
@@ -777,10 +794,11 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_s_barrier();
         } else if constexpr (VAR & VAR_GLDS) {
+            const bool live = tile_live(j);
             if constexpr (!(VAR & ABL_NO_DMA)) {
                 if (j + 1 < nt) dma_tile(IC<BUF ^ 1>{}, j + 1);   // lands in the other buffer under this tile's math
             }
-            if (tile_live(j)) compute_tile(bufc, j * BLOCK_N);
+            if (live) compute_tile(bufc, j * BLOCK_N);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed ...
             __builtin_amdgcn_s_waitcnt(0xC07F);               // (lgkmcnt(0): this wave's LDS reads are done)
             if constexpr (!(VAR & ABL_NO_BARRIER)) __builtin_amdgcn_s_barrier();   // ... and so have everybody else's
@@ -792,6 +810,7 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
         }
     };
 
+    fetch_bits(0);
     if (nt > 0) {
         if constexpr (VAR & VAR_GLDS) {
             dma_tile(IC<0>{}, 0);

@@ -243,12 +243,36 @@ int pfa_device_supported(int device_id) {
     return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
 }
 
-// [B,Sk] key masks are condensed into one 64-bit word per batch and 64-key tile before the forward (fa3_keybits_kernel)
-static size_t keybits_bytes(const pfa_fa3_args* a) {
-    return a->key_mask ? (size_t)a->B * (size_t)((a->Sk + 63) / 64) * sizeof(unsigned long long) : 0;
+// Masks are condensed into one 64-bit word per mask row and 64-key tile before the forward (fa3_maskbits_kernel): geometry of
+// the word array for `a` -- the mask's own (un-broadcast) extents and the word strides the kernels use
+struct MaskBits {
+    int Bm = 0, Hm = 0, Qm = 0, nt = 0;
+    int64_t sb = 0, sh = 0, sq = 0, sk = 0;      // byte strides of the source mask
+    int64_t ob = 0, oh = 0, oq = 0;              // word strides of the result (0 = broadcast)
+    const uint8_t* src = nullptr;
+    size_t bytes() const { return src ? (size_t)Bm * Hm * Qm * nt * sizeof(unsigned long long) : 0; }
+};
+static MaskBits mask_bits(const pfa_fa3_args* a) {
+    MaskBits m;
+    m.nt = (a->Sk + 63) / 64;
+    if (a->key_mask) {
+        m.src = a->key_mask; m.Bm = a->B; m.Hm = 1; m.Qm = 1;
+        m.sb = a->key_mask_stride_b; m.sk = 1;
+    } else if (a->mask) {
+        m.src = a->mask;
+        m.Bm = a->mask_stride_b ? a->B : 1; m.Hm = a->mask_stride_h ? a->H : 1; m.Qm = a->mask_stride_q ? a->Sq : 1;
+        m.sb = a->mask_stride_b; m.sh = a->mask_stride_h; m.sq = a->mask_stride_q; m.sk = a->mask_stride_k;
+    } else {
+        return m;
+    }
+    if (m.Qm > 65535 || (int64_t)m.Bm * m.Hm > 65535) { m.src = nullptr; return m; }      // launch limits: the byte path serves these
+    m.oq = m.Qm > 1 ? m.nt : 0;
+    m.oh = m.Hm > 1 ? (int64_t)m.Qm * m.nt : 0;
+    m.ob = m.Bm > 1 ? (int64_t)m.Hm * m.Qm * m.nt : 0;
+    return m;
 }
 
-size_t pfa_fa3_workspace_bytes(const pfa_fa3_args* a) { return a ? keybits_bytes(a) : 0; }
+size_t pfa_fa3_workspace_bytes(const pfa_fa3_args* a) { return a ? mask_bits(a).bytes() : 0; }
 
 int pfa_fa3_check(const pfa_fa3_args* a) { return check(a); }
 
@@ -282,10 +306,11 @@ int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream) {
     p.o_sb = a->o_stride_b; p.o_sh = a->o_stride_h; p.o_ss = a->o_stride_s;
     p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
     p.dbg = (unsigned long long*)a->workspace;   // only the diagnostic VAR_STAMP variant writes it
-    // key mask + enough workspace: one word per tile instead of a mask byte per score (without workspace the byte path runs)
-    const bool use_kbits = a->key_mask && a->workspace && a->workspace_bytes >= keybits_bytes(a);
-    p.kbits = use_kbits ? (const unsigned long long*)a->workspace : nullptr;
-    p.kbits_nt = (a->Sk + 63) / 64;
+    // mask + enough workspace: one word per row and tile instead of a mask byte per score (without workspace the byte path runs)
+    const MaskBits mb = mask_bits(a);
+    const bool use_mbits = mb.src && a->workspace && a->workspace_bytes >= mb.bytes();
+    p.mbits = use_mbits ? (const unsigned long long*)a->workspace : nullptr;
+    p.mb_sb = mb.ob; p.mb_sh = mb.oh; p.mb_sq = mb.oq;
     const Variant v = pick(a);
     p.nqblk = (a->Sq + v.block_m - 1) / v.block_m;
     p.kv_group = a->kv_group > 1 ? a->kv_group : 1;
@@ -313,9 +338,10 @@ int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream) {
         (void)hipGetLastError();
         return PFA_ERR_DEVICE;
     }
-    if (use_kbits) {
-        hipLaunchKernelGGL(pfa::fa3_keybits_kernel<0>, dim3((unsigned)((p.kbits_nt + 3) / 4), (unsigned)a->B), dim3(256), 0, (hipStream_t)stream,
-                           a->key_mask, a->key_mask_stride_b, a->Sk, p.kbits_nt, (unsigned long long*)a->workspace);
+    if (use_mbits) {
+        hipLaunchKernelGGL(pfa::fa3_maskbits_kernel<0>, dim3((unsigned)((mb.nt + 3) / 4), (unsigned)mb.Qm, (unsigned)(mb.Bm * mb.Hm)), dim3(256), 0,
+                           (hipStream_t)stream, mb.src, mb.sb, mb.sh, mb.sq, mb.sk, mb.Hm, a->Sk, mb.nt, (unsigned long long*)a->workspace,
+                           mb.ob, mb.oh, mb.oq);
         if (hipGetLastError() != hipSuccess) {
             if (prev_dev != a->device_id) (void)hipSetDevice(prev_dev);
             return PFA_ERR_LAUNCH;

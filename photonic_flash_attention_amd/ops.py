@@ -77,7 +77,13 @@ def _as_mask4(mask: torch.Tensor, B: int, H: int, Sq: int, Sk: int, device) -> t
             raise ValueError(f"mask dim {name} is {got}, expected 1 or {want}")
     if mask.shape[3] != Sk:
         mask = mask.expand(-1, -1, -1, Sk)
-    m = (mask != 0).to(device=device, dtype=torch.uint8)
+    dev = device if isinstance(device, torch.device) else torch.device(device)
+    if mask.dtype == torch.bool and mask.device == dev:
+        m = mask.view(torch.uint8)            # bools are 0 / 1 bytes already: no conversion pass over the mask
+    elif mask.dtype == torch.uint8 and mask.device == dev:
+        m = mask                              # the kernels test for non-zero
+    else:
+        m = (mask != 0).to(device=device, dtype=torch.uint8)
     if m.stride(3) not in (0, 1) or (m.shape[3] > 1 and m.stride(3) == 0):
         m = m.contiguous()
     return m
@@ -130,12 +136,6 @@ def build_args(q, k, v, out, *, causal=False, seqlens_k=None, key_mask=None, sof
             km = (km != 0).to(device=q.device, dtype=torch.uint8).contiguous()
         a.key_mask = km.data_ptr()
         a.key_mask_stride_b = km.stride(0)
-        # scratch for the per-tile mask words (pfa_fa3_workspace_bytes): with it a padding mask costs what seqlens_k costs
-        ws_bytes = int(_capi.load().pfa_fa3_workspace_bytes(C.byref(a)))
-        if ws_bytes:
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
-            a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
-            keep.append(ws)
         keep.append(km)
     if mask is not None:
         if key_mask is not None:
@@ -145,6 +145,14 @@ def build_args(q, k, v, out, *, causal=False, seqlens_k=None, key_mask=None, sof
         st = [0 if m4.shape[i] == 1 else m4.stride(i) for i in range(4)]
         a.mask_stride_b, a.mask_stride_h, a.mask_stride_q, a.mask_stride_k = st[0], st[1], st[2], (st[3] or 1)
         keep.append(m4)
+    if key_mask is not None or mask is not None:
+        # scratch for the mask condensed to one 64-bit word per row and 64-key tile (pfa_fa3_workspace_bytes; optional for the
+        # C ABI, always given here): a padding mask then costs about what seqlens_k costs, an element mask 1/3 of the byte path
+        ws_bytes = int(_capi.load().pfa_fa3_workspace_bytes(C.byref(a)))
+        if ws_bytes:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
+            keep.append(ws)
     if lse is not None:
         if lse.shape != (B, H, Sq) or lse.dtype != torch.float32 or not lse.is_contiguous():
             raise ValueError("lse must be contiguous fp32 [B, H, Sq]")
