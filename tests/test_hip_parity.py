@@ -376,3 +376,35 @@ def test_head_dims_without_a_kernel_run_zero_padded(D, causal):
     assert float((o2.permute(0, 2, 1, 3).float().cpu() - ref).abs().max()) <= 2e-2     # bf16 store
     with pytest.raises(ValueError):
         ops.fa3_forward(*(torch.zeros(1, 1, 64, 256, device=DEV, dtype=torch.bfloat16) for _ in range(3)))
+
+
+@pytest.mark.parametrize("kind", ["key", "b1qk", "bhqk", "11qk", "3d"])
+@pytest.mark.parametrize("causal", [False, True])
+def test_mask_words_and_mask_bytes_agree(kind, causal):
+    """The C ABI reads a mask either as 64-bit words condensed into the caller's workspace (pfa_fa3_workspace_bytes) or, without
+    workspace, a byte per score: both paths must give the same bits, for every broadcast shape of the reference's masks."""
+    import ctypes as C
+    from photonic_flash_attention_amd import _capi, ops, synth
+    dev = _dev()
+    B, H, Sq, Sk, D = 2, 3, 200, 330, 64
+    q, k, v = (t.to(dev).permute(0, 2, 1, 3) for t in synth.qkv(B, H, Sq, Sk, D, 9100, "bf16"))
+    g = torch.Generator().manual_seed(3)
+    shape = {"key": (B, Sk), "b1qk": (B, 1, Sq, Sk), "bhqk": (B, H, Sq, Sk), "11qk": (1, 1, Sq, Sk), "3d": (B, Sq, Sk)}[kind]
+    m = torch.rand(shape, generator=g) < 0.6
+    m[..., :70] = True                    # tile 0 fully visible (the all-ones shortcut) ...
+    m[..., 128:192] = False               # ... tile 2 fully masked (skipped) ...
+    m = m.to(dev)                         # ... the others mixed (bit tests)
+    outs = []
+    for with_ws in (True, False):
+        out = torch.empty(B, Sq, H, D, device=dev, dtype=torch.float32).permute(0, 2, 1, 3)
+        lse = torch.empty(B, H, Sq, device=dev, dtype=torch.float32)
+        kw = dict(key_mask=m) if kind == "key" else dict(mask=m)
+        a, keep = ops.build_args(q, k, v, out, causal=causal, lse=lse, **kw)
+        assert a.workspace_bytes == _capi.load().pfa_fa3_workspace_bytes(C.byref(a)) > 0
+        if not with_ws:
+            a.workspace, a.workspace_bytes = None, 0
+        assert _capi.load().pfa_fa3_fwd(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+        torch.cuda.synchronize()
+        outs.append((out.clone(), lse.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(torch.nan_to_num(outs[0][1], neginf=-1e30), torch.nan_to_num(outs[1][1], neginf=-1e30))
