@@ -30,6 +30,8 @@ struct WeightsParams {
     int32_t nqblk;
     int32_t kv_group;
     float scale_log2;
+    const unsigned long long* mbits;   // mask condensed to words (FwdParams::mbits), or null: bytes
+    int64_t mb_sb, mb_sh, mb_sq;
 };
 
 template <typename T, int D, bool CAUSAL, bool KMASK, typename WT>
@@ -66,6 +68,7 @@ __global__ __launch_bounds__(256) void fa3_weights_kernel(const WeightsParams p)
         int my_q;
         bool dead;
         const uint8_t* mp;
+        const unsigned long long* mw;      // the row's mask words (one per 64 keys), or null
     };
     auto load_strip = [&](Strip& S, int s) {
         S.my_q = q0 + 32 * s + r;
@@ -76,6 +79,7 @@ __global__ __launch_bounds__(256) void fa3_weights_kernel(const WeightsParams p)
         S.lse2 = lse * 1.4426950408889634f;
         S.dead = !(lse > -INFINITY);
         S.mp = KMASK ? p.mask + (int64_t)b * p.m_sb + (int64_t)hh * p.m_sh + (int64_t)qrow * p.m_sq : nullptr;
+        S.mw = (KMASK && p.mbits) ? p.mbits + (int64_t)b * p.mb_sb + (int64_t)hh * p.mb_sh + (int64_t)qrow * p.mb_sq : nullptr;
     };
     auto load_k = [&](int key_base, v8 (&kf)[KS]) {      // lane (key r, h): K[key][16 ks + 8 h .. +7]
         const int krow = min(key_base + r, p.Sk - 1);
@@ -90,12 +94,19 @@ __global__ __launch_bounds__(256) void fa3_weights_kernel(const WeightsParams p)
         for (int e = 0; e < 16; ++e) s[e] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) s = E::mfma(kf[ks], S.qf[ks], s);
+        uint32_t mbits32 = 0;                    // the lane's mask bits of this 32-key block (words path)
+        if constexpr (KMASK) {
+            if (S.mw) mbits32 = (uint32_t)(S.mw[key_base >> 6] >> ((key_base & 32) + 4 * h));
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int key = key_base + (e & 3) + 8 * (e >> 2) + 4 * h;
             bool ok = key < kv_len && !S.dead;
             if (CAUSAL) ok = ok && (key <= S.my_q);
-            if (KMASK) ok = ok && (S.mp[(int64_t)min(key, p.Sk - 1) * p.m_sk] != 0);
+            if (KMASK) {
+                if (S.mw) ok = ok && (((mbits32 >> ((e & 3) + 8 * (e >> 2))) & 1u) != 0);
+                else ok = ok && (S.mp[(int64_t)min(key, p.Sk - 1) * p.m_sk] != 0);
+            }
             w[e] = ok ? fast_exp2(__builtin_fmaf(s[e], c, -S.lse2)) : 0.f;
         }
     };

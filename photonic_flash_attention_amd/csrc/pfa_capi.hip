@@ -272,6 +272,13 @@ static MaskBits mask_bits(const pfa_fa3_args* a) {
     return m;
 }
 
+static bool launch_mask_bits(const MaskBits& mb, const pfa_fa3_args* a, void* stream) {
+    hipLaunchKernelGGL(pfa::fa3_maskbits_kernel<0>, dim3((unsigned)((mb.nt + 3) / 4), (unsigned)mb.Qm, (unsigned)(mb.Bm * mb.Hm)), dim3(256), 0,
+                       (hipStream_t)stream, mb.src, mb.sb, mb.sh, mb.sq, mb.sk, mb.Hm, a->Sk, mb.nt, (unsigned long long*)a->workspace,
+                       mb.ob, mb.oh, mb.oq);
+    return hipGetLastError() == hipSuccess;
+}
+
 size_t pfa_fa3_workspace_bytes(const pfa_fa3_args* a) { return a ? mask_bits(a).bytes() : 0; }
 
 int pfa_fa3_check(const pfa_fa3_args* a) { return check(a); }
@@ -338,14 +345,9 @@ int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream) {
         (void)hipGetLastError();
         return PFA_ERR_DEVICE;
     }
-    if (use_mbits) {
-        hipLaunchKernelGGL(pfa::fa3_maskbits_kernel<0>, dim3((unsigned)((mb.nt + 3) / 4), (unsigned)mb.Qm, (unsigned)(mb.Bm * mb.Hm)), dim3(256), 0,
-                           (hipStream_t)stream, mb.src, mb.sb, mb.sh, mb.sq, mb.sk, mb.Hm, a->Sk, mb.nt, (unsigned long long*)a->workspace,
-                           mb.ob, mb.oh, mb.oq);
-        if (hipGetLastError() != hipSuccess) {
-            if (prev_dev != a->device_id) (void)hipSetDevice(prev_dev);
-            return PFA_ERR_LAUNCH;
-        }
+    if (use_mbits && !launch_mask_bits(mb, a, stream)) {
+        if (prev_dev != a->device_id) (void)hipSetDevice(prev_dev);
+        return PFA_ERR_LAUNCH;
     }
     if (v.lds_bytes > 64 * 1024)   // opt in to > 64 KiB of dynamic LDS (idempotent, per function)
         (void)hipFuncSetAttribute(v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, v.lds_bytes);
@@ -384,6 +386,10 @@ int pfa_fa3_weights(const pfa_fa3_args* a, void* w, int32_t w_dtype, int64_t w_s
     p.nqblk = (a->Sq + 127) / 128;
     p.kv_group = a->kv_group > 1 ? a->kv_group : 1;
     p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
+    const MaskBits mb = mask_bits(a);          // as in pfa_fa3_fwd: the mask as words when the caller gave workspace
+    const bool use_mbits = mb.src && a->workspace && a->workspace_bytes >= mb.bytes();
+    p.mbits = use_mbits ? (const unsigned long long*)a->workspace : nullptr;
+    p.mb_sb = mb.ob; p.mb_sh = mb.oh; p.mb_sq = mb.oq;
     const bool causal = a->causal != 0, kmask = p.mask != nullptr, w32 = w_dtype == PFA_DTYPE_FP32;
     const void* fn;
     if (a->dtype_in == PFA_DTYPE_BF16)
@@ -397,6 +403,10 @@ int pfa_fa3_weights(const pfa_fa3_args* a, void* w, int32_t w_dtype, int64_t w_s
         g_last_hip_error = (int)e;
         (void)hipGetLastError();
         return PFA_ERR_DEVICE;
+    }
+    if (use_mbits && !launch_mask_bits(mb, a, stream)) {      // (again: the call may come without a forward before it)
+        if (prev_dev != a->device_id) (void)hipSetDevice(prev_dev);
+        return PFA_ERR_LAUNCH;
     }
     void* kargs[] = {&p};
     e = hipLaunchKernel(fn, dim3((unsigned)(p.nqblk * a->B * a->H)), dim3(256), kargs, 0, (hipStream_t)stream);
