@@ -41,6 +41,10 @@ struct BwdParams {
     int64_t dq_sb, dq_sh, dq_ss, dk_sb, dk_sh, dk_ss, dv_sb, dv_sh, dv_ss;
     int32_t B, H, Sq, Sk;
     int32_t nblk;          // Q blocks (dq) or key blocks (dkdv)
+    // a mask that depends on the key only ([B,Sk]: strides over heads and rows are 0) needs no KMASK kernels: the dK/dV kernel folds it
+    // into its per-lane "this key exists" flag, the dQ kernel reads it four keys per load
+    const uint8_t* keymask;     // u8 [B][Sk], 0 = masked; or null
+    int64_t km_sb;              // byte stride between batches (keys contiguous; host: Sk, base and stride multiples of 4)
     float scale;           // softmax scale
     float scale_log2;      // scale * log2(e)
 };
@@ -332,8 +336,19 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
         }
         __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
         // masks only where a tile crosses the diagonal or the key tail (wave-uniform, a real branch)
-        if (KMASK || (key_base + BLOCK_N > kv_len) || (CAUSAL && key_base + BLOCK_N - 1 > wave_q0)) {
+        if (KMASK || p.keymask || (key_base + BLOCK_N > kv_len) || (CAUSAL && key_base + BLOCK_N - 1 > wave_q0)) {
             asm volatile("" ::: "memory");
+            // key-only mask: the lane's 32 keys of the tile are 8 groups of 4 consecutive keys = 8 dword loads (the same for the 32
+            // lanes of a half-wave), where the element-mask path reads a byte per score.  Keys past Sk: the key < kv_len test.
+            uint32_t kmw[2][4];
+            if (p.keymask) {
+                const uint8_t* kmrow = p.keymask + (int64_t)b * p.km_sb;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        kmw[kb][g] = *(const uint32_t*)(kmrow + min(key_base + 32 * kb + 8 * g + 4 * h, p.Sk - 4));
+            }
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -342,6 +357,7 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
                     bool ok = key < kv_len;
                     if (CAUSAL) ok = ok && (key <= my_q);
                     if (KMASK) ok = ok && (mrow[(int64_t)min(key, p.Sk - 1) * p.m_sk] != 0);
+                    if (p.keymask) ok = ok && (((kmw[kb][e >> 2] >> (8 * (e & 3))) & 0xFFu) != 0);
                     s[kb][e] = ok ? s[kb][e] : -INFINITY;
                 }
         }
@@ -436,7 +452,8 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
 
     int kv_len = p.Sk;
     if (p.seqlens_k) kv_len = min(kv_len, max(p.seqlens_k[b], 0));
-    const bool key_ok = my_key < kv_len;
+    // (a masked key behaves like one past kv_len: its column feeds only its own dK / dV, which are stored as zeros)
+    const bool key_ok = my_key < kv_len && (!p.keymask || p.keymask[(int64_t)b * p.km_sb + min(my_key, p.Sk - 1)] != 0);
     // query tiles this block needs: causal -> rows >= k0
     const int t_first = CAUSAL ? (k0 / BLOCK_N) : 0;
     const int nt = (p.Sq + BLOCK_N - 1) / BLOCK_N;

@@ -79,11 +79,17 @@ int pfa_fa3_bwd(const pfa_fa3_bwd_args* a, void* stream) {
     p.dk_sb = a->dk_stride_b; p.dk_sh = a->dk_stride_h; p.dk_ss = a->dk_stride_s;
     p.dv_sb = a->dv_stride_b; p.dv_sh = a->dv_stride_h; p.dv_ss = a->dv_stride_s;
     p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
+    // a mask of the keys only (the reference's 2-D [B,Sk] mask arrives as [B,1,1,Sk]) runs on the unmasked kernels: see BwdParams::keymask
+    const bool key_only = a->mask && a->mask_stride_h == 0 && a->mask_stride_q == 0 && a->mask_stride_k == 1 && a->Sk % 4 == 0 &&
+                          a->mask_stride_b % 4 == 0 && ((uintptr_t)a->mask & 3) == 0;
+    p.keymask = key_only ? a->mask : nullptr;
+    p.km_sb = a->mask_stride_b;
+    if (key_only) p.mask = nullptr;
     p.scale = a->softmax_scale;
     p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
 
     const void *kdelta, *kdq, *kdkdv;
-    const bool causal = a->causal != 0, g32 = a->dtype_grad == PFA_DTYPE_FP32, kmask = a->mask != nullptr;
+    const bool causal = a->causal != 0, g32 = a->dtype_grad == PFA_DTYPE_FP32, kmask = p.mask != nullptr;     // (not for key-only masks)
     if (a->dtype == PFA_DTYPE_BF16) {
         if (a->D == 128) pick_kernels<__bf16, 128>(causal, kmask, g32, kdelta, kdq, kdkdv);
         else pick_kernels<__bf16, 64>(causal, kmask, g32, kdelta, kdq, kdkdv);
