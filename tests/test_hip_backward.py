@@ -138,7 +138,9 @@ def _torch_ref_masked(q, k, v, dout, keep, scale):
 MASK_CASES = [
     # B, H, Sq, Sk, D, causal, kind
     (2, 2, 128, 128, 64, False, "key"),
-    (1, 2, 200, 333, 128, False, "key"),
+    (1, 2, 200, 333, 128, False, "key"),          # Sk % 4 != 0: the element-mask kernels
+    (2, 2, 300, 640, 128, True, "key"),           # key-only masks on the unmasked kernels (Sk % 4 == 0), causal, ragged Sq
+    (3, 1, 130, 1028, 64, False, "key"),
     (2, 3, 192, 192, 128, False, "b1qk"),
     (1, 2, 320, 320, 64, True, "bhqk"),
     (1, 2, 256, 256, 128, False, "dead_rows"),
