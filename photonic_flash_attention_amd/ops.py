@@ -56,6 +56,23 @@ def is_available(device: Optional[torch.device] = None) -> bool:
     return lib.pfa_device_supported(int(idx)) == 1
 
 
+_SEQLENS_CACHE: "dict[tuple, torch.Tensor]" = {}
+
+
+def _seqlens_tensor(seqlens_k, device) -> torch.Tensor:
+    """``seqlens_k`` as a contiguous int32 device tensor.  Python lists are uploaded once per distinct value (a pageable
+    host-to-device copy costs ~15 us per call, more than the C2 kernel); tensors are used as they are."""
+    if isinstance(seqlens_k, torch.Tensor):
+        return seqlens_k.to(device=device, dtype=torch.int32).contiguous()
+    key = (tuple(int(x) for x in seqlens_k), str(device))
+    t = _SEQLENS_CACHE.get(key)
+    if t is None:
+        if len(_SEQLENS_CACHE) >= 64:
+            _SEQLENS_CACHE.clear()
+        t = _SEQLENS_CACHE[key] = torch.tensor(key[0], dtype=torch.int32, device=device)
+    return t
+
+
 def _bhsd_strides(t: torch.Tensor):
     sb, sh, ss, sd = t.stride()
     if sd != 1 and t.shape[3] != 1:
@@ -121,7 +138,7 @@ def build_args(q, k, v, out, *, causal=False, seqlens_k=None, key_mask=None, sof
     )
     keep = []
     if seqlens_k is not None:
-        sl = torch.as_tensor(seqlens_k, dtype=torch.int32, device=q.device).contiguous()
+        sl = _seqlens_tensor(seqlens_k, q.device)
         if sl.numel() != B:
             raise ValueError("seqlens_k must have B entries")
         a.seqlens_k = sl.data_ptr()
@@ -268,7 +285,7 @@ def fa3_backward(q, k, v, out, dout, lse, *, causal: bool = False, seqlens_k=Non
     a.lse, a.delta = lse.data_ptr(), delta.data_ptr()
     keep = [delta]
     if seqlens_k is not None:
-        sl = torch.as_tensor(seqlens_k, dtype=torch.int32, device=q.device).contiguous()
+        sl = _seqlens_tensor(seqlens_k, q.device)
         a.seqlens_k = sl.data_ptr()
         keep.append(sl)
     if key_mask is not None:
