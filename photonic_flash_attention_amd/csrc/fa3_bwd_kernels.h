@@ -43,6 +43,7 @@ struct BwdParams {
     int32_t nblk;          // Q blocks (dq) or key blocks (dkdv)
     // a mask that depends on the key only ([B,Sk]: strides over heads and rows are 0) needs no KMASK kernels: the dK/dV kernel folds it
     // into its per-lane "this key exists" flag, the dQ kernel reads it four keys per load
+    int32_t mask_dw;            // element mask rows are 4-byte aligned and Sk % 4 == 0: the dQ kernel reads them four keys per load
     const uint8_t* keymask;     // u8 [B][Sk], 0 = masked; or null
     int64_t km_sb;              // byte stride between batches (keys contiguous; host: Sk, base and stride multiples of 4)
     float scale;           // softmax scale
@@ -341,8 +342,9 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
             // key-only mask: the lane's 32 keys of the tile are 8 groups of 4 consecutive keys = 8 dword loads (the same for the 32
             // lanes of a half-wave), where the element-mask path reads a byte per score.  Keys past Sk: the key < kv_len test.
             uint32_t kmw[2][4];
-            if (p.keymask) {
-                const uint8_t* kmrow = p.keymask + (int64_t)b * p.km_sb;
+            const bool dwords = p.keymask || (KMASK && p.mask_dw);
+            if (dwords) {
+                const uint8_t* kmrow = p.keymask ? p.keymask + (int64_t)b * p.km_sb : mrow;
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -356,8 +358,8 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
                     const int key = key_base + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
                     bool ok = key < kv_len;
                     if (CAUSAL) ok = ok && (key <= my_q);
-                    if (KMASK) ok = ok && (mrow[(int64_t)min(key, p.Sk - 1) * p.m_sk] != 0);
-                    if (p.keymask) ok = ok && (((kmw[kb][e >> 2] >> (8 * (e & 3))) & 0xFFu) != 0);
+                    if (dwords) ok = ok && (((kmw[kb][e >> 2] >> (8 * (e & 3))) & 0xFFu) != 0);
+                    else if (KMASK) ok = ok && (mrow[(int64_t)min(key, p.Sk - 1) * p.m_sk] != 0);
                     s[kb][e] = ok ? s[kb][e] : -INFINITY;
                 }
         }
@@ -530,6 +532,16 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
                 }
             }
         }
+        // element mask: the 16 bytes (column my_key, rows of this half) are requested BEFORE the MFMAs so that their latency runs
+        // under them; read where they are used, each half paid a full memory round trip
+        uint32_t mbyte[16];
+        if constexpr (KMASK) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int qi = min(q_base + (e & 3) + 8 * (e >> 2) + 4 * h, p.Sq - 1);
+                mbyte[e] = mcol[(int64_t)qi * p.m_sq];
+            }
+        }
         // (a pinned prefetch ring as in the dQ kernel costs 20 spilled registers here and doubles the run time: the two
         //  workgroups per CU cover the read latency instead)
         static_for<KS>([&](auto ksc) {
@@ -548,12 +560,9 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[e] = (t <= (e & 3) + 8 * (e >> 2)) ? s[e] : -INFINITY;
         }
-        if constexpr (KMASK) {                  // element mask: column my_key, rows of this half
+        if constexpr (KMASK) {                  // element mask: column my_key, rows of this half (bytes fetched before the MFMAs above)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int qi = min(q_base + (e & 3) + 8 * (e >> 2) + 4 * h, p.Sq - 1);
-                s[e] = (mcol[(int64_t)qi * p.m_sq] != 0) ? s[e] : -INFINITY;
-            }
+            for (int e = 0; e < 16; ++e) s[e] = (mbyte[e] != 0) ? s[e] : -INFINITY;
         }
         // dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]   (16 query rows per s2)
         static_for<2>([&](auto s2c) {

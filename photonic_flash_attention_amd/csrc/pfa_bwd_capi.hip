@@ -85,6 +85,8 @@ int pfa_fa3_bwd(const pfa_fa3_bwd_args* a, void* stream) {
     p.keymask = key_only ? a->mask : nullptr;
     p.km_sb = a->mask_stride_b;
     if (key_only) p.mask = nullptr;
+    p.mask_dw = (p.mask && a->mask_stride_k == 1 && a->Sk % 4 == 0 && a->mask_stride_b % 4 == 0 && a->mask_stride_h % 4 == 0 &&
+                 a->mask_stride_q % 4 == 0 && ((uintptr_t)a->mask & 3) == 0) ? 1 : 0;
     p.scale = a->softmax_scale;
     p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
 
