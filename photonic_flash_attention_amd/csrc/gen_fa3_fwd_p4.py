@@ -1,0 +1,1017 @@
+#!/usr/bin/env python3
+"""gen_fa3_fwd_p4.py -- generator of the PERSISTENT 4-wave Flash-Attention forward for gfx950, as assembly.
+
+    python3 gen_fa3_fwd_p4.py > build/fa3_fwd_p4.s        (the Makefile assembles it into the code object that libpfa_hip.so embeds)
+
+Replaces the reference's tile loop (core/flash_attention_3.py:207-260) on the shapes pfa_capi.hip routes here (D = 128, Sq a
+multiple of 256 [512 under a causal mask], Sk a multiple of 128, no mask, no seqlens): the same math, LDS images and MFMA operand
+maps as fa3_fwd_w4_kernel.h (4 waves x 64 query rows, one wave per SIMD, S^T = K Q^T and O^T += V^T P^T on
+v_mfma_f32_32x32x16, online softmax with defer-max), but
+
+  * PERSISTENT: one workgroup per CU walks a static list of (head, Q block) items; the K/V LDS-DMA ring keeps running across
+    the item seam (the last two iterations of an item already fetch tiles 0 / 1 of the next one), the next item's Q rows are
+    fetched into their landing zone during the current item's first four tiles, the output leaves through LDS as whole rows.
+    Under a causal mask a unit is the (heaviest, lightest) open block pair of a head, so the static shares are equal; the units
+    of a head are dealt to consecutive CUs of ONE XCD, which therefore stream that head's K/V in lockstep (L2 serves all but one).
+  * every instruction of the tile loop is placed by this script: one MFMA per gap plus its fillers, LDS reads waited for in
+    pairs (8 s_waitcnt per phase instead of 16), one M0 write per four DMA pieces (a wave's pieces are contiguous in LDS, the
+    piece index rides in the instruction's immediate offset), the tile offset in the load's scalar offset (no VALU), no
+    compiler-inserted s_nop / v_mov; the rare paths (O rescale, diagonal mask, a wave's last tile) sit out of line.
+
+Register plan (per wave, 512 registers):
+    a[0:63] O of strip A, a[64:127] O of strip B, a[128:159] / a[160:191] the Q fragments of A / B
+    v[16:143] S, double buffered: buf0 A, buf0 B, buf1 A, buf1 B (32 each: key block 0, key block 1)
+    v[144:175] P (packed bf16) of A / B, v[176:191] K fragment ring, v[192:207] V^T fragment ring, v[208:] addresses and state
+"""
+import sys
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# LDS map (bytes): K ring 2 x 16 KiB, V ring 2 x 16 KiB, Q landing zone 4 waves x 16 KiB, O staging 4 waves x 8 KiB = 160 KiB
+TILE = 16384
+K_BASE, V_BASE, Q_BASE, O_BASE = 0, 2 * TILE, 4 * TILE, 8 * TILE
+LDS_BYTES = 8 * TILE + 4 * 8192
+HALF = TILE // 2
+
+# kernarg dwords (struct pfa::P4Params in pfa_p4.hip -- static_asserted there against these offsets)
+KA = dict(q=0, k=2, v=4, o=6, lse=8, q_sb=10, q_sh=11, k_sb=12, k_sh=13, v_sb=14, v_sh=15, o_sb=16, o_sh=17,
+          q_ss=18, k_ss=19, v_ss=20, o_ss=21, H=22, Sq=23, Sk=24, NB=25, NU=26, magic_NU=27, magic_H=28, kv_group=29,
+          magic_G=30, scale_log2=31, thr=32, hx=33, xcd_mode=34, SL=35, nt_full=36, pad=37, dbg=38)
+KARG_DWORDS = 40
+KBASE_SGPR = 60                     # kernargs live in s[60:99]
+
+
+def ka(name, n=1, hi=False):
+    i = KBASE_SGPR + KA[name] + (1 if hi else 0)
+    return f"s{i}" if n == 1 else f"s[{i}:{i + n - 1}]"
+
+
+class SAlloc:
+    def __init__(self, first, last):
+        self.next, self.last, self.names = first, last, {}
+
+    def new(self, name, n=1, align=1):
+        while self.next % align:
+            self.next += 1
+        base = self.next
+        self.next += n
+        assert self.next - 1 <= self.last, f"out of SGPRs at {name}"
+        self.names[name] = (base, n)
+        return base
+
+    def __call__(self, name, i=None, n=None):
+        base, cnt = self.names[name]
+        if i is not None:
+            return f"s{base + i}" if n is None else f"s[{base + i}:{base + i + n - 1}]"
+        return f"s{base}" if cnt == 1 else f"s[{base}:{base + cnt - 1}]"
+
+
+S = SAlloc(3, KBASE_SGPR - 1)
+for nm, n, al in [("wave", 1, 1), ("ksrd", 4, 4), ("vsrd", 4, 4), ("qsrd_n", 4, 4), ("osrd", 4, 4), ("lsrd", 4, 4),
+                  ("ksrd_n", 2, 2), ("vsrd_n", 2, 2), ("grow", 2, 2), ("t2", 2, 2),
+                  ("koff", 1, 1), ("voff", 1, 1), ("ktile", 1, 1), ("vtile", 1, 1), ("krem", 1, 1), ("vrem", 1, 1),
+                  ("qrem", 1, 1), ("wrem", 1, 1), ("irem", 1, 1), ("nt_n", 1, 1), ("qdst", 1, 1), ("qoff", 1, 1),
+                  ("t0", 1, 1), ("t1", 1, 1), ("t3", 1, 1), ("w4k", 1, 1), ("xcd", 1, 1), ("slot", 1, 1), ("Ux", 1, 1),
+                  ("n_u", 1, 1), ("n_sub", 1, 1), ("n_valid", 1, 1), ("n_qblk", 1, 1), ("n_b", 1, 1), ("n_hh", 1, 1), ("n_nt", 1, 1)]:
+    S.new(nm, n, al)
+
+
+# VGPR plan
+def SBUF(buf, X, kb, e):            # S accumulator register of buffer buf (0/1), strip X ('A'/'B'), key block kb, element e
+    return 16 + 64 * buf + (0 if X == 'A' else 32) + 16 * kb + e
+
+
+def PD(X, i):
+    return 144 + (0 if X == 'A' else 16) + i
+
+
+KFR = lambda i: 176 + 4 * (i % 4)
+VFR = lambda i: 192 + 4 * (i % 4)
+KOFF = lambda ks: 208 + ks
+VOFF = lambda db, hi: 216 + 2 * db + hi
+KDOFF = lambda t: 224 + t
+VDOFF = lambda t: 228 + t
+QDOFF = lambda t: 232 + t
+ST = {"m": 0, "l": 1, "mc": 2, "thr": 3, "al": 4, "ps0": 5}
+
+
+def STV(X, f):
+    return 236 + (0 if X == 'A' else 6) + ST[f]
+
+
+V_PS1 = 248
+V_MX = 249
+V_T = [250, 251, 252, 253]
+V_TA = 254            # causal: r + 1 - 4h (element-mask threshold of the diagonal tile, see mask_diag)
+V_LANE = 255
+V_E = list(range(0, 16))   # prologue / epilogue / rescale scratch (v0 = workitem id at entry)
+OA = lambda X, db, e=0: (0 if X == 'A' else 64) + 16 * db + e
+QA = lambda X, ks: 128 + (0 if X == 'A' else 32) + 4 * ks
+NEG_BIG = "0xf149f2ca"     # -1e30f
+NEG_INF = "0xff800000"
+
+
+def vr(base, n=1):
+    return f"v{base}" if n == 1 else f"v[{base}:{base + n - 1}]"
+
+
+def ar(base, n=1):
+    return f"a{base}" if n == 1 else f"a[{base}:{base + n - 1}]"
+
+
+class Lgkm:
+    """Outstanding LDS reads in issue order -> counted s_waitcnt lgkmcnt(N)."""
+
+    def __init__(self):
+        self.q = []
+
+    def issue(self, tag):
+        self.q.append(tag)
+
+    def need(self, tags):
+        idx = [self.q.index(t) for t in tags if t in self.q]
+        if not idx:
+            return None
+        i = max(idx)
+        n = len(self.q) - 1 - i
+        self.q = self.q[i + 1:]
+        return f"s_waitcnt lgkmcnt({n})"
+
+
+class Gen:
+    def __init__(self, dtype, causal, out32=False):
+        self.dt, self.causal, self.out32 = dtype, causal, out32
+        self.mf = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
+        self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
+        self.name = f"fa3_fwd_p4_{dtype}_{'causal' if causal else 'full'}_{'o32' if out32 else 'o16'}"
+        self.main, self.ool = [], []
+        self.L = self.main
+        self.uid = 0
+
+    # ---- emission helpers ------------------------------------------------------------------------------------------------
+    def i(self, s):
+        self.L.append("\t" + s)
+
+    def lab(self, s):
+        self.L.append(f"{s}:")
+
+    def cm(self, s):
+        self.L.append(f"\t; {s}")
+
+    def ul(self, stem):
+        self.uid += 1
+        return f".L{self.name}_{stem}_{self.uid}"
+
+    def emit(self, lst):
+        for x in lst:
+            self.i(x)
+
+    def out_of_line(self, on):
+        self.L = self.ool if on else self.main
+
+    # ---- building blocks -------------------------------------------------------------------------------------------------
+    def kread(self, slot, i):                 # K fragment i = (kb, ks) of the K tile in ring slot `slot` -> ring register i % 4
+        kb, ks = i // 8, i % 8
+        return f"ds_read_b128 {vr(KFR(i), 4)}, {vr(KOFF(ks))} offset:{K_BASE + slot * TILE + kb * HALF}"
+
+    def vread(self, slot, idx):               # V^T fragment idx = (f, db): two transposed 8-byte reads (rows +0 / +8)
+        f, db = idx // 4, idx % 4
+        ko = slot * TILE + (f // 2) * HALF + (f & 1) * 16 * 256
+        b = VFR(idx)
+        return [f"ds_read_b64_tr_b16 {vr(b, 2)}, {vr(VOFF(db, 0))} offset:{ko}",
+                f"ds_read_b64_tr_b16 {vr(b + 2, 2)}, {vr(VOFF(db, 1))} offset:{ko}"]
+
+    def dma(self, which, t):                  # piece t of this wave's four (M0 already points at the wave's 4 KiB of the slot)
+        off, srd, so = (KDOFF(t), S("ksrd"), S("koff")) if which == 'K' else (VDOFF(t), S("vsrd"), S("voff"))
+        return f"buffer_load_dwordx4 {vr(off)}, {srd}, {so} offen offset:{1024 * t} lds"
+
+    def setm0(self, which, slot):             # M0 = this wave's 4 KiB of ring slot `slot` of the K / V ring  (clobbers SCC)
+        return f"s_add_u32 m0, {S('w4k')}, {(K_BASE if which == 'k' else V_BASE) + slot * TILE}"
+
+    # softmax FINISH of strip X on buffer `buf`: the exponentials of key block 1 and all sixteen P dwords
+    def finish_fill(self, X, buf, e):
+        c1 = lambda k: vr(SBUF(buf, X, 1, k))
+        c0 = lambda k: vr(SBUF(buf, X, 0, k))
+        o = [f"v_fma_f32 {c1(e)}, {c1(e)}, {ka('scale_log2')}, -{vr(STV(X, 'mc'))}", f"v_exp_f32 {c1(e)}, {c1(e)}"]
+        if e == 0:
+            o.append(f"v_add_f32 {vr(STV(X, 'ps0'))}, {vr(STV(X, 'ps0'))}, {c0(15)}")
+        if e % 2 == 0:
+            o.append(f"{self.cvt} {vr(PD(X, e // 2))}, {c0(e)}, {c0(e + 1)}")
+            if e >= 4:
+                o.append(f"v_add_f32 {vr(V_PS1)}, {vr(V_PS1)}, {c1(e - 4)}")
+                o.append(f"v_add_f32 {vr(V_PS1)}, {vr(V_PS1)}, {c1(e - 3)}")
+        elif e >= 3:
+            o.append(f"{self.cvt} {vr(PD(X, 8 + (e - 3) // 2))}, {c1(e - 3)}, {c1(e - 2)}")
+        return o
+
+    def finish_end(self, X, buf):
+        c1 = lambda k: vr(SBUF(buf, X, 1, k))
+        o = [f"v_add_f32 {vr(V_PS1)}, {vr(V_PS1)}, {c1(k)}" for k in range(12, 16)]
+        o.append(f"{self.cvt} {vr(PD(X, 15))}, {c1(14)}, {c1(15)}")
+        o.append(f"v_add_f32 {vr(STV(X, 'l'))}, {vr(STV(X, 'l'))}, {vr(STV(X, 'ps0'))}")
+        o.append(f"v_add_f32 {vr(STV(X, 'l'))}, {vr(STV(X, 'l'))}, {vr(V_PS1)}")
+        o.append(f"v_mov_b32 {vr(V_PS1)}, 0")
+        return o
+
+    # softmax START of strip X on buffer `buf`, step u = 0..15 (row max, defer-max update, exponentials of key block 0)
+    def start_fill(self, X, buf, u):
+        n0 = lambda k: vr(SBUF(buf, X, 0, k))
+        mx, m, l, mc, th, al, ps0 = vr(V_MX), *(vr(STV(X, f)) for f in ("m", "l", "mc", "thr", "al", "ps0"))
+        t0, t1 = vr(V_T[0]), vr(V_T[1])
+        o = []
+        if u < 4:
+            kb, o8 = u >> 1, (u & 1) * 8
+            s = lambda k: vr(SBUF(buf, X, kb, o8 + k))
+            if u == 0:
+                o.append(f"v_max3_f32 {mx}, {s(0)}, {s(1)}, {s(2)}")
+                o.append(f"v_max3_f32 {mx}, {mx}, {s(3)}, {s(4)}")
+                o.append(f"v_max3_f32 {mx}, {mx}, {s(5)}, {s(6)}")
+                o.append(f"v_max_f32 {mx}, {mx}, {s(7)}")
+            else:
+                for k in range(0, 8, 2):
+                    o.append(f"v_max3_f32 {mx}, {mx}, {s(k)}, {s(k + 1)}")
+            if u == 3:                       # the lane pair that shares a query row (VALU write -> permlane read: 2 wait states)
+                o += [f"v_mov_b32 {t0}, {mx}", "s_nop 1", f"v_permlane32_swap_b32 {mx}, {t0}", f"v_max_f32 {mx}, {mx}, {t0}"]
+        elif u == 4:
+            # branch-free, per row: a max inside the headroom leaves m alone, and then alpha = exp2(0) = 1 exactly
+            o += [f"v_cmp_gt_f32 vcc, {mx}, {th}",
+                  f"s_or_b64 {S('grow')}, {S('grow')}, vcc",
+                  f"v_mov_b32 {ps0}, 0",
+                  f"v_cndmask_b32 {t0}, {m}, {mx}, vcc",                  # m_new
+                  f"v_sub_f32 {t1}, {m}, {t0}",
+                  f"v_mul_f32 {t1}, {ka('scale_log2')}, {t1}",
+                  f"v_exp_f32 {al}, {t1}",
+                  f"v_mov_b32 {m}, {t0}",
+                  f"v_add_f32 {th}, {ka('thr')}, {t0}",
+                  f"v_mul_f32 {mc}, {ka('scale_log2')}, {t0}",
+                  f"v_mul_f32 {l}, {l}, {al}"]
+        else:
+            v = u - 5
+            lo, n = (v // 2) * 3 + (v & 1), (2 if (v & 1) else 1)
+            nprev = 0 if v == 0 else (1 if (v & 1) else 2)
+            for e in range(lo, lo + n):
+                o.append(f"v_fma_f32 {n0(e)}, {n0(e)}, {ka('scale_log2')}, -{mc}")
+            for e in range(lo, lo + n):
+                o.append(f"v_exp_f32 {n0(e)}, {n0(e)}")
+            for e in range(lo - nprev, lo):
+                o.append(f"v_add_f32 {ps0}, {ps0}, {n0(e)}")
+        return o
+
+    def qk_mfma(self, buf, X, i):
+        kb, ks = i // 8, i % 8
+        acc = vr(SBUF(buf, X, kb, 0), 16)
+        return f"{self.mf} {acc}, {vr(KFR(i), 4)}, {ar(QA(X, ks), 4)}, {'0' if ks == 0 else acc}"
+
+    def pv_mfma(self, X, idx):
+        f, db = idx // 4, idx % 4
+        acc = ar(OA(X, db), 16)
+        return f"{self.mf} {acc}, {vr(VFR(idx), 4)}, {vr(PD(X, 4 * f), 4)}, {acc}"
+
+    # ---- phases ----------------------------------------------------------------------------------------------------------
+    def phase_qk(self, p, fillers, dma_at, lg=None, pre=(), tail_vreads=None):
+        """QK^T(j+1) into buffer 1-p from K slot 1-p; fillers[hs] = instructions for the gap behind MFMA hs.  tail_vreads = V slot
+        whose first four V^T fragments are requested in the last gaps (after the last K read), for the PV phase that follows."""
+        nb, slot = 1 - p, 1 - p
+        lg = lg or Lgkm()
+        for i in range(4):
+            self.i(self.kread(slot, i))
+            lg.issue(('k', i))
+        self.emit(pre)
+        for hs in range(32):
+            i, X = hs // 2, 'AB'[hs % 2]
+            if hs % 2 == 0 and i % 2 == 0:
+                w = lg.need([('k', i), ('k', i + 1)])
+                if w:
+                    self.i(w)
+            self.i(self.qk_mfma(nb, X, i))
+            if hs % 2 == 1 and i % 2 == 1:
+                for f in (i + 3, i + 4):
+                    if f < 16:
+                        self.i(self.kread(slot, f))
+                        lg.issue(('k', f))
+            if tail_vreads is not None and hs >= 28:
+                for k, x in enumerate(self.vread(tail_vreads, hs - 28)):
+                    self.i(x)
+                    lg.issue(('v', hs - 28, k))
+            self.emit(dma_at.get(hs, []))
+            self.emit(fillers[hs])
+        return lg
+
+    def phase_pv(self, p, fillers, dma_at, strips="AB", lg=None, preissued=False):
+        """PV(j): P dwords x V slot p -> O; fillers as above."""
+        slot = p
+        lg = lg or Lgkm()
+        if not preissued:
+            for idx in range(4):
+                for k, x in enumerate(self.vread(slot, idx)):
+                    self.i(x)
+                    lg.issue(('v', idx, k))
+        hs = 0
+        for idx in range(16):
+            if idx % 2 == 0:
+                w = lg.need([('v', idx, 1), ('v', idx + 1, 1)])
+                if w:
+                    self.i(w)
+            for X in strips:
+                self.i(self.pv_mfma(X, idx))
+                if X == strips[-1] and idx % 2 == 1:
+                    for f in (idx + 3, idx + 4):
+                        if f < 16:
+                            for k, x in enumerate(self.vread(slot, f)):
+                                self.i(x)
+                                lg.issue(('v', f, k))
+                self.emit(dma_at.get(hs, []))
+                self.emit(fillers[hs] if hs < len(fillers) else [])
+                hs += 1
+        return lg
+
+    # ---- DMA stream bookkeeping (top and bottom of every iteration, all body kinds; workgroup-uniform) -----------------------------
+    def stream_top(self):
+        l1, l2 = self.ul("kok"), self.ul("vok")
+        self.i(f"s_cmp_lg_u32 {S('krem')}, 0")
+        self.i(f"s_cbranch_scc1 {l1}")
+        self.i(f"s_mov_b64 {S('ksrd', 0, 2)}, {S('ksrd_n')}")           # K(j+2) is tile 0 of the next item
+        self.i(f"s_mov_b32 {S('koff')}, 0")
+        self.i(f"s_mov_b32 {S('krem')}, {S('nt_n')}")
+        self.lab(l1)
+        self.i(f"s_cmp_lg_u32 {S('vrem')}, 0")
+        self.i(f"s_cbranch_scc1 {l2}")
+        self.i(f"s_mov_b64 {S('vsrd', 0, 2)}, {S('vsrd_n')}")
+        self.i(f"s_mov_b32 {S('voff')}, 0")
+        self.i(f"s_mov_b32 {S('vrem')}, {S('nt_n')}")
+        self.lab(l2)
+
+    def stream_bottom(self):
+        """Q pieces of the next item (first four iterations of an item), the counted wait, the barrier."""
+        lq, lb = self.ul("q"), self.ul("bar")
+        self.i(f"s_add_u32 {S('koff')}, {S('koff')}, {S('ktile')}")
+        self.i(f"s_add_u32 {S('voff')}, {S('voff')}, {S('vtile')}")
+        self.i(f"s_sub_u32 {S('krem')}, {S('krem')}, 1")
+        self.i(f"s_sub_u32 {S('vrem')}, {S('vrem')}, 1")
+        self.i(f"s_sub_u32 {S('wrem')}, {S('wrem')}, 1")
+        self.i(f"s_cmp_lg_u32 {S('qrem')}, 0")
+        self.i(f"s_cbranch_scc1 {lq}")
+        self.i("s_waitcnt vmcnt(0)")
+        self.lab(lb)
+        self.i("s_barrier")
+        self.out_of_line(True)
+        self.lab(lq)
+        self.q_group()
+        self.i("s_waitcnt vmcnt(4)")            # everything but the four Q pieces just issued
+        self.i(f"s_branch {lb}")
+        self.out_of_line(False)
+
+    def q_group(self):
+        """Four 1-KiB pieces (16 whole rows) of this wave's share of the NEXT item's Q block -> its landing zone."""
+        self.i(f"s_mov_b32 m0, {S('qdst')}")
+        self.i(f"s_sub_u32 {S('qrem')}, {S('qrem')}, 1")
+        for t in range(4):
+            self.i(f"buffer_load_dwordx4 {vr(QDOFF(t))}, {S('qsrd_n')}, {S('qoff')} offen offset:{1024 * t} lds")
+        self.i(f"s_add_u32 {S('qdst')}, {S('qdst')}, 4096")
+        self.i(f"s_lshl_b32 {S('t0')}, {ka('q_ss')}, 4")
+        self.i(f"s_add_u32 {S('qoff')}, {S('qoff')}, {S('t0')}")
+
+    # ---- bodies ----------------------------------------------------------------------------------------------------------
+    def dma_plan(self, p, gaps_v, gaps_k):
+        """V(j+1) -> V slot 1-p, K(j+2) -> K slot p: {gap: [instructions]}"""
+        d = {}
+        for n, g in enumerate(gaps_v):
+            d.setdefault(g, [])
+            if n == 0:
+                d[g] += [self.setm0('v', 1 - p), "s_nop 0"]          # M0 write -> LDS-DMA: one wait state
+            d[g].append(self.dma('V', n))
+        for n, g in enumerate(gaps_k):
+            d.setdefault(g, [])
+            if n == 0:
+                d[g] += [self.setm0('k', p), "s_nop 0"]
+            d[g].append(self.dma('K', n))
+        return d
+
+    def body_full(self, p):
+        self.cm(f"FULL body, parity {p}: QK^T(j+1) || softmax finish(j);  PV(j) || softmax start(j+1)")
+        fa = []
+        for hs in range(32):
+            X, e = ('A', hs) if hs < 16 else ('B', hs - 16)
+            f = self.finish_fill(X, p, e)
+            if hs == 16:
+                f = self.finish_end('A', p) + f
+            fa.append(f)
+        # the first gap's fillers run while the first K fragments are on their way
+        pre, fa[0] = fa[0], []
+        # V pieces early in the QK^T phase, K pieces late: each lands well before the barrier
+        lg = self.phase_qk(p, fa, self.dma_plan(p, [1, 5, 9, 13], [17, 21, 25, 27]), pre=pre, tail_vreads=p)
+        self.emit(self.finish_end('B', p))
+        if self.causal:                        # the diagonal tile of this wave is tile wnt-1 = j+1  <=>  wrem == 1
+            lm, lr = self.ul("mask"), self.ul("masked")
+            self.i(f"s_cmp_eq_u32 {S('wrem')}, 1")
+            self.i(f"s_cbranch_scc1 {lm}")
+            self.lab(lr)
+            self.out_of_line(True)
+            self.lab(lm)
+            self.mask_diag(1 - p)
+            self.i(f"s_branch {lr}")
+            self.out_of_line(False)
+        fb = []
+        for hs in range(32):
+            X, u = ('A', hs) if hs < 16 else ('B', hs - 16)
+            fb.append(self.start_fill(X, 1 - p, u))
+        self.phase_pv(p, fb, {}, lg=lg, preissued=True)
+        # pending O rescale (rare: defer-max)
+        lr, lb = self.ul("rescale"), self.ul("rescaled")
+        self.i(f"s_cmp_lg_u64 {S('grow')}, 0")
+        self.i(f"s_cbranch_scc1 {lr}")
+        self.lab(lb)
+        self.out_of_line(True)
+        self.lab(lr)
+        self.rescale()
+        self.i(f"s_branch {lb}")
+        self.out_of_line(False)
+
+    def body_last(self, p):
+        self.cm(f"LAST body, parity {p}: this wave's last tile -- finish(j), PV(j); nothing to prefetch for the wave itself")
+        d = self.dma_plan(p, [0, 2, 4, 6], [8, 10, 12, 14])
+        for e in range(16):
+            self.emit(self.finish_fill('A', p, e))
+        self.emit(self.finish_end('A', p))
+        self.i("s_nop 1")
+        fb = [self.finish_fill('B', p, e) for e in range(16)]
+        self.phase_pv(p, fb, d, strips="A")
+        self.emit(self.finish_end('B', p))
+        self.i("s_nop 1")
+        self.phase_pv(p, [[] for _ in range(16)], {}, strips="B")
+
+    def body_skip(self, p):
+        self.cm(f"SKIP body, parity {p}: this wave is past its last tile of the item -- keep the rings fed")
+        self.i(self.setm0('v', 1 - p))
+        self.i("s_nop 0")
+        for t in range(4):
+            self.i(self.dma('V', t))
+        self.i(self.setm0('k', p))
+        self.i("s_nop 0")
+        for t in range(4):
+            self.i(self.dma('K', t))
+
+    def mask_diag(self, buf):
+        """Causal mask of the wave's diagonal tile (key base = the wave's first row): key 32 kb + kidx(e) + 4h is visible to row
+        r of strip A iff 32 kb + kidx < r + 1 - 4h = tA, to row r of strip B iff 32 kb + kidx < tA + 32.  So strip A key block 0
+        and strip B key block 1 are partial with the SAME lane test, strip A key block 1 is masked whole, strip B key block 0
+        is visible whole."""
+        self.i("s_nop 7")
+        self.i("s_nop 7")                     # last QK^T MFMA -> VALU access of S
+        ninf = vr(V_T[3])                     # (a literal and VCC together exceed the constant bus)
+        self.i(f"v_mov_b32 {ninf}, {NEG_INF}")
+        for e in range(16):
+            kidx = (e & 3) + 8 * (e >> 2)
+            self.i(f"v_cmp_gt_i32 vcc, {vr(V_TA)}, {kidx}")
+            self.i(f"v_mov_b32 {vr(SBUF(buf, 'A', 1, e))}, {ninf}")
+            self.i("s_nop 0")
+            self.i(f"v_cndmask_b32 {vr(SBUF(buf, 'A', 0, e))}, {ninf}, {vr(SBUF(buf, 'A', 0, e))}, vcc")
+            self.i(f"v_cndmask_b32 {vr(SBUF(buf, 'B', 1, e))}, {ninf}, {vr(SBUF(buf, 'B', 1, e))}, vcc")
+
+    def rescale(self):
+        """O *= alpha (per row; 1 exactly where the row max stayed inside its headroom)."""
+        self.i("s_nop 15")
+        self.i("s_nop 15")                    # last PV MFMA -> v_accvgpr_read
+        for X in "AB":
+            al = vr(STV(X, 'al'))
+            for b0 in range(0, 64, 4):
+                regs = [OA(X, 0) + b0 + k for k in range(4)]
+                for k, a in enumerate(regs):
+                    self.i(f"v_accvgpr_read_b32 {vr(V_E[k])}, a{a}")
+                for k in range(4):
+                    self.i(f"v_mul_f32 {vr(V_E[k])}, {vr(V_E[k])}, {al}")
+                for k, a in enumerate(regs):
+                    self.i(f"v_accvgpr_write_b32 a{a}, {vr(V_E[k])}")
+        self.i("s_nop 7")
+        self.i(f"s_mov_b64 {S('grow')}, 0")
+
+    # ---- item decode: unit counter / sub item -> bases, descriptors, tile count (SALU only) ----------------------------------------
+    def decode(self):
+        """In: n_u = unit counter i of the item to decode, n_sub its sub item (causal: 0 heavy block, 1 light block).
+        Out: ksrd_n / vsrd_n (bases), qsrd_n, n_nt, n_qblk, n_b, n_hh, n_valid.  A counter past the workgroup's list leaves the
+        descriptors as they are (the stream then re-fetches tiles of a valid item: harmless) and gives n_valid = 0, n_nt = maxint."""
+        u, t0, t1, t3 = S('t3'), S('t0'), S('t1'), S('t2', 0)
+        th = S('t2', 1)
+        lv, ln = self.ul("valid"), self.ul("decoded")
+        # u = slot + SL * i  (the units of this XCD's heads, head-major, dealt round-robin over its CUs: a head's units run on
+        # consecutive CUs at the same time)
+        self.i(f"s_mul_i32 {u}, {S('n_u')}, {ka('SL')}")
+        self.i(f"s_add_u32 {u}, {u}, {S('slot')}")
+        self.i(f"s_cmp_lt_u32 {u}, {S('Ux')}")
+        self.i(f"s_cbranch_scc1 {lv}")
+        self.i(f"s_mov_b32 {S('n_nt')}, 0x7fffffff")
+        self.i(f"s_mov_b32 {S('n_valid')}, 0")
+        self.i(f"s_branch {ln}")
+        self.lab(lv)
+        self.i(f"s_mov_b32 {S('n_valid')}, 1")
+        # lh = u / NU, p = u % NU
+        self.i(f"s_mul_hi_u32 {t0}, {u}, {ka('magic_NU')}")
+        self.i(f"s_cmp_eq_u32 {ka('NU')}, 1")
+        self.i(f"s_cselect_b32 {t0}, {u}, {t0}")                       # lh
+        self.i(f"s_mul_i32 {t1}, {t0}, {ka('NU')}")
+        self.i(f"s_sub_u32 {t1}, {u}, {t1}")                           # p
+        if self.causal:
+            self.i(f"s_sub_u32 {t3}, {ka('NB')}, 1")
+            self.i(f"s_sub_u32 {t3}, {t3}, {t1}")                      # heavy block NB-1-p
+            self.i(f"s_cmp_eq_u32 {S('n_sub')}, 0")
+            self.i(f"s_cselect_b32 {t1}, {t3}, {t1}")                  # qblk
+            self.i(f"s_add_u32 {t3}, {t1}, 1")
+            self.i(f"s_lshl_b32 {S('n_nt')}, {t3}, 2")                 # nt = 4 (qblk + 1)
+        else:
+            self.i(f"s_mov_b32 {S('n_nt')}, {ka('nt_full')}")
+        self.i(f"s_mov_b32 {S('n_qblk')}, {t1}")
+        # bh = xcd_mode ? xcd + 8 lh : lh
+        self.i(f"s_lshl_b32 {t3}, {t0}, 3")
+        self.i(f"s_add_u32 {t3}, {t3}, {S('xcd')}")
+        self.i(f"s_cmp_eq_u32 {ka('xcd_mode')}, 0")
+        self.i(f"s_cselect_b32 {t0}, {t0}, {t3}")                      # bh
+        # b = bh / H, hh = bh % H, hkv = hh / kv_group
+        self.i(f"s_mul_hi_u32 {t1}, {t0}, {ka('magic_H')}")
+        self.i(f"s_cmp_eq_u32 {ka('H')}, 1")
+        self.i(f"s_cselect_b32 {t1}, {t0}, {t1}")                      # b
+        self.i(f"s_mul_i32 {t3}, {t1}, {ka('H')}")
+        self.i(f"s_sub_u32 {t0}, {t0}, {t3}")                          # hh
+        self.i(f"s_mov_b32 {S('n_b')}, {t1}")
+        self.i(f"s_mov_b32 {S('n_hh')}, {t0}")
+        self.i(f"s_mul_hi_u32 {u}, {t0}, {ka('magic_G')}")
+        self.i(f"s_cmp_eq_u32 {ka('kv_group')}, 1")
+        self.i(f"s_cselect_b32 {u}, {t0}, {u}")                        # hkv
+        # K / V bases: ptr + b * sb + hkv * sh (byte strides, 32-bit)
+        for nm, sr in (('k', 'ksrd_n'), ('v', 'vsrd_n')):
+            lo, hi = S(sr, 0), S(sr, 1)
+            self.i(f"s_mul_i32 {lo}, {t1}, {ka(nm + '_sb')}")
+            self.i(f"s_mul_hi_u32 {hi}, {t1}, {ka(nm + '_sb')}")
+            self.i(f"s_mul_i32 {t3}, {u}, {ka(nm + '_sh')}")
+            self.i(f"s_mul_hi_u32 {th}, {u}, {ka(nm + '_sh')}")
+            self.i(f"s_add_u32 {lo}, {lo}, {t3}")
+            self.i(f"s_addc_u32 {hi}, {hi}, {th}")
+            self.i(f"s_add_u32 {lo}, {lo}, {ka(nm)}")
+            self.i(f"s_addc_u32 {hi}, {hi}, {ka(nm, hi=True)}")
+            self.i(f"s_and_b32 {hi}, {hi}, 0xffff")
+        # Q descriptor: base = ptr + b * sb + hh * sh + qblk * 256 * ss  (records / flags are set once in the kernel prologue)
+        lo, hi = S('qsrd_n', 0), S('qsrd_n', 1)
+        self.i(f"s_mul_i32 {lo}, {t1}, {ka('q_sb')}")
+        self.i(f"s_mul_hi_u32 {hi}, {t1}, {ka('q_sb')}")
+        self.i(f"s_mul_i32 {t3}, {t0}, {ka('q_sh')}")
+        self.i(f"s_mul_hi_u32 {th}, {t0}, {ka('q_sh')}")
+        self.i(f"s_add_u32 {lo}, {lo}, {t3}")
+        self.i(f"s_addc_u32 {hi}, {hi}, {th}")
+        self.i(f"s_lshl_b32 {u}, {S('n_qblk')}, 8")
+        self.i(f"s_mul_i32 {t3}, {u}, {ka('q_ss')}")
+        self.i(f"s_mul_hi_u32 {th}, {u}, {ka('q_ss')}")
+        self.i(f"s_add_u32 {lo}, {lo}, {t3}")
+        self.i(f"s_addc_u32 {hi}, {hi}, {th}")
+        self.i(f"s_add_u32 {lo}, {lo}, {ka('q')}")
+        self.i(f"s_addc_u32 {hi}, {hi}, {ka('q', hi=True)}")
+        self.i(f"s_and_b32 {hi}, {hi}, 0xffff")
+        self.lab(ln)
+
+    def make_out_srds(self):
+        """osrd / lsrd of the item that becomes current, from n_b / n_hh / n_qblk (before the next decode overwrites them)."""
+        t0, t1, t3, th = S('t0'), S('t1'), S('t2', 0), S('t2', 1)
+        lo, hi = S('osrd', 0), S('osrd', 1)
+        self.i(f"s_mul_i32 {lo}, {S('n_b')}, {ka('o_sb')}")
+        self.i(f"s_mul_hi_u32 {hi}, {S('n_b')}, {ka('o_sb')}")
+        self.i(f"s_mul_i32 {t3}, {S('n_hh')}, {ka('o_sh')}")
+        self.i(f"s_mul_hi_u32 {th}, {S('n_hh')}, {ka('o_sh')}")
+        self.i(f"s_add_u32 {lo}, {lo}, {t3}")
+        self.i(f"s_addc_u32 {hi}, {hi}, {th}")
+        self.i(f"s_lshl_b32 {t0}, {S('n_qblk')}, 8")
+        self.i(f"s_mul_i32 {t3}, {t0}, {ka('o_ss')}")
+        self.i(f"s_mul_hi_u32 {th}, {t0}, {ka('o_ss')}")
+        self.i(f"s_add_u32 {lo}, {lo}, {t3}")
+        self.i(f"s_addc_u32 {hi}, {hi}, {th}")
+        self.i(f"s_add_u32 {lo}, {lo}, {ka('o')}")
+        self.i(f"s_addc_u32 {hi}, {hi}, {ka('o', hi=True)}")
+        self.i(f"s_and_b32 {hi}, {hi}, 0xffff")
+        # lse: base = lse + ((b * H + hh) * Sq + qblk * 256) * 4
+        self.i(f"s_mul_i32 {t1}, {S('n_b')}, {ka('H')}")
+        self.i(f"s_add_u32 {t1}, {t1}, {S('n_hh')}")
+        self.i(f"s_mul_i32 {t3}, {t1}, {ka('Sq')}")
+        self.i(f"s_mul_hi_u32 {th}, {t1}, {ka('Sq')}")
+        self.i(f"s_add_u32 {t3}, {t3}, {t0}")
+        self.i(f"s_addc_u32 {th}, {th}, 0")
+        self.i(f"s_lshl_b64 {S('t2')}, {S('t2')}, 2")
+        self.i(f"s_add_u32 {S('lsrd', 0)}, {ka('lse')}, {t3}")
+        self.i(f"s_addc_u32 {S('lsrd', 1)}, {ka('lse', hi=True)}, {th}")
+        self.i(f"s_and_b32 {S('lsrd', 1)}, {S('lsrd', 1)}, 0xffff")
+
+    # ---- per-item prologue and epilogue ------------------------------------------------------------------------------------------
+    def item_prologue(self):
+        """Q fragments out of the landing zone into the accumulator file, state, QK^T(0) (O zeroed in its shadow), softmax start(0)."""
+        self.cm("item prologue")
+        self.i("s_waitcnt vmcnt(16)")         # this item's Q pieces: everything but the previous item's 16 output stores (issued after them)
+        qb = V_E[0:8]        # per-lane addresses of the Q fragments (recomputed per item: nothing lane-constant is kept live for it)
+        T0, T1, T2 = (vr(x) for x in V_T[0:3])
+        # address = qland + r * 256 + (((2 ks + h) ^ (r & 15)) << 4)  =  rowbase ^ (32 ks),  qland = Q_BASE + wave * 16384
+        self.i(f"s_lshl_b32 {S('t0')}, {S('w4k')}, 2")
+        self.i(f"s_add_u32 {S('t0')}, {S('t0')}, {Q_BASE}")
+        self.i(f"v_and_b32 {T0}, 31, {vr(V_LANE)}")                               # r
+        self.i(f"v_lshrrev_b32 {T1}, 5, {vr(V_LANE)}")                            # h
+        self.i(f"v_and_b32 {T2}, 15, {T0}")
+        self.i(f"v_xor_b32 {T2}, {T2}, {T1}")
+        self.i(f"v_lshlrev_b32 {T2}, 4, {T2}")
+        self.i(f"v_lshl_add_u32 {T2}, {T0}, 8, {T2}")
+        self.i(f"v_add_u32 {T2}, {S('t0')}, {T2}")
+        for ks in range(8):
+            self.i(f"v_xor_b32 {vr(qb[ks])}, {32 * ks}, {T2}")
+        for X, off in (('A', 0), ('B', 8192)):
+            for ks in range(8):
+                self.i(f"ds_read_b128 {ar(QA(X, ks), 4)}, {vr(qb[ks])} offset:{off}")
+        for X in "AB":
+            self.i(f"v_mov_b32 {vr(STV(X, 'm'))}, {NEG_BIG}")
+            self.i(f"v_mov_b32 {vr(STV(X, 'thr'))}, {NEG_BIG}")
+            self.i(f"v_mul_f32 {vr(STV(X, 'mc'))}, {ka('scale_log2')}, {vr(STV(X, 'm'))}")
+            self.i(f"v_mov_b32 {vr(STV(X, 'l'))}, 0")
+            self.i(f"v_mov_b32 {vr(STV(X, 'ps0'))}, 0")
+            self.i(f"v_mov_b32 {vr(STV(X, 'al'))}, 1.0")
+        self.i(f"v_mov_b32 {vr(V_PS1)}, 0")
+        self.i("s_waitcnt lgkmcnt(0)")
+        # QK^T(0) from K slot 0 into buffer 0; four O zeros per gap
+        zero = [[f"v_accvgpr_write_b32 a{4 * hs + k}, 0" for k in range(4)] for hs in range(32)]
+        self.phase_qk(1, zero, {})            # parity argument 1: target buffer 0, K slot 0
+        if self.causal:
+            lm, lr = self.ul("mask0"), self.ul("masked0")
+            self.i(f"s_cmp_eq_u32 {S('wrem')}, 0")          # wnt == 1: tile 0 is this wave's diagonal tile
+            self.i(f"s_cbranch_scc1 {lm}")
+            self.lab(lr)
+            self.out_of_line(True)
+            self.lab(lm)
+            self.mask_diag(0)
+            self.i(f"s_branch {lr}")
+            self.out_of_line(False)
+        self.i("s_nop 7")
+        self.i("s_nop 7")
+        for X in "AB":
+            for u in range(16):
+                self.emit(self.start_fill(X, 0, u))
+        for X in "AB":
+            self.i(f"v_mov_b32 {vr(STV(X, 'al'))}, 1.0")
+        self.i(f"s_mov_b64 {S('grow')}, 0")
+
+    def item_epilogue(self):
+        """Normalise, convert, stage the strip as a [32 rows][256 B] image in the wave's own LDS, store whole rows; LSE."""
+        self.cm("item epilogue")
+        self.i("s_nop 15")
+        self.i("s_nop 15")                    # last MFMA -> v_accvgpr_read
+        vb, rb = V_E[8], V_E[9:13]            # staging write base, read-back bases
+        inv, lt, t = V_E[13], V_E[14], V_E[15]
+        L, T0, T1, T2, T3 = vr(V_LANE), *(vr(x) for x in V_T)
+        gofs = V_PS1
+        self.i(f"s_lshl_b32 {S('t0')}, {S('w4k')}, 1")
+        self.i(f"s_add_u32 {S('t0')}, {S('t0')}, {O_BASE}")                       # ostage = O_BASE + wave * 8192
+        # write base: ostage + r * 256 + ((h ^ (r & 15)) << 4)   (chunk 4 db + g + h lands at ((4 db + g) << 4) ^ that)
+        self.i(f"v_and_b32 {T0}, 31, {L}")
+        self.i(f"v_lshrrev_b32 {T1}, 5, {L}")
+        self.i(f"v_and_b32 {T2}, 15, {T0}")
+        self.i(f"v_xor_b32 {T2}, {T2}, {T1}")
+        self.i(f"v_lshlrev_b32 {T2}, 4, {T2}")
+        self.i(f"v_lshl_add_u32 {T2}, {T0}, 8, {T2}")
+        self.i(f"v_add_u32 {vr(vb)}, {S('t0')}, {T2}")
+        # LSE offset of the lane's row inside the item: (64 wave + r) * 4
+        self.i(f"s_lshr_b32 {S('t1')}, {S('w4k')}, 4")
+        self.i(f"v_lshlrev_b32 {T3}, 2, {T0}")
+        self.i(f"v_add_u32 {T3}, {S('t1')}, {T3}")
+        # read-back bases: ostage + (4 k + q4) * 256 + ((c16 ^ (4 k + q4)) << 4), k = 0..3; rows 16 further: + 4096
+        self.i(f"v_lshrrev_b32 {T0}, 4, {L}")                                   # q4
+        self.i(f"v_and_b32 {T1}, 15, {L}")                                      # c16
+        for k in range(4):
+            self.i(f"v_add_u32 {T2}, {4 * k}, {T0}")                              # row
+            self.i(f"v_xor_b32 {vr(rb[k])}, {T1}, {T2}")
+            self.i(f"v_lshlrev_b32 {vr(rb[k])}, 4, {vr(rb[k])}")
+            self.i(f"v_lshl_add_u32 {vr(rb[k])}, {T2}, 8, {vr(rb[k])}")
+            self.i(f"v_add_u32 {vr(rb[k])}, {S('t0')}, {vr(rb[k])}")
+        # store offset inside the item's output rows: (64 wave + q4) * o_ss + 16 c16
+        self.i(f"s_lshr_b32 {S('t1')}, {S('w4k')}, 6")                             # 64 wave
+        self.i(f"v_add_u32 {T0}, {S('t1')}, {T0}")
+        self.i(f"v_mul_lo_u32 {vr(gofs)}, {T0}, {ka('o_ss')}")
+        self.i(f"v_lshl_add_u32 {vr(gofs)}, {T1}, 4, {vr(gofs)}")
+        self.i(f"s_lshl_b32 {S('t1')}, {ka('o_ss')}, 2")                           # four rows
+        for X in "AB":
+            l, mc = vr(STV(X, 'l')), vr(STV(X, 'mc'))
+            self.i(f"v_mov_b32 {vr(t)}, {l}")
+            self.i("s_nop 1")
+            self.i(f"v_permlane32_swap_b32 {l}, {vr(t)}")
+            self.i(f"v_add_f32 {vr(lt)}, {l}, {vr(t)}")
+            self.i(f"v_rcp_f32 {vr(inv)}, {vr(lt)}")
+            self.i(f"v_cmp_lt_f32 vcc, 0, {vr(lt)}")
+            self.i("s_nop 1")
+            self.i(f"v_cndmask_b32 {vr(inv)}, 0, {vr(inv)}, vcc")
+            w = V_E[0:8]
+            for db in range(4):
+                for g in (0, 2):
+                    for k in range(8):
+                        self.i(f"v_accvgpr_read_b32 {vr(w[k])}, a{OA(X, db, 4 * g + k)}")
+                    for k in range(8):
+                        self.i(f"v_mul_f32 {vr(w[k])}, {vr(w[k])}, {vr(inv)}")
+                    # ua = (w0 w1 | w2 w3), ub = (w4 w5 | w6 w7) -> registers w0 w1 (ua) and w2 w3 (ub) after conversion
+                    self.i(f"{self.cvt} {vr(w[0])}, {vr(w[0])}, {vr(w[1])}")
+                    self.i(f"{self.cvt} {vr(w[1])}, {vr(w[2])}, {vr(w[3])}")
+                    self.i(f"{self.cvt} {vr(w[2])}, {vr(w[4])}, {vr(w[5])}")
+                    self.i(f"{self.cvt} {vr(w[3])}, {vr(w[6])}, {vr(w[7])}")
+                    self.i(f"v_xor_b32 {vr(w[4])}, {(4 * db + g) << 4}, {vr(vb)}")
+                    self.i("s_nop 0")
+                    self.i(f"v_permlane32_swap_b32 {vr(w[0])}, {vr(w[2])}")
+                    self.i(f"v_permlane32_swap_b32 {vr(w[1])}, {vr(w[3])}")
+                    self.i(f"ds_write_b128 {vr(w[4])}, {vr(w[0], 4)}")
+            # LSE = (m c + log2(l)) ln 2, stored by the lower lane half (one lane per row)
+            self.i(f"v_log_f32 {vr(t)}, {vr(lt)}")
+            self.i(f"v_mov_b32 {vr(inv)}, {NEG_INF}")
+            self.i(f"v_add_f32 {vr(t)}, {vr(t)}, {mc}")
+            self.i(f"v_mul_f32 {vr(t)}, 0x3f317218, {vr(t)}")
+            self.i(f"v_cndmask_b32 {vr(t)}, {vr(inv)}, {vr(t)}, vcc")
+            ll = self.ul("nolse")
+            self.i(f"s_cmp_eq_u64 {ka('lse', 2)}, 0")
+            self.i(f"s_cbranch_scc1 {ll}")
+            self.i("s_mov_b32 exec_hi, 0")
+            self.i(f"buffer_store_dword {vr(t)}, {T3}, {S('lsrd')}, 0 offen offset:{0 if X == 'A' else 128}")
+            self.i("s_mov_b32 exec_hi, -1")
+            self.lab(ll)
+            self.i("s_waitcnt lgkmcnt(0)")
+            x = [16 + 4 * k for k in range(8)]                  # S buffer 0 is dead here: eight 16-byte read-back registers
+            for k in range(8):
+                self.i(f"ds_read_b128 {vr(x[k], 4)}, {vr(rb[k & 3])} offset:{(k >> 2) * 4096}")
+            if X == 'A':
+                self.i(f"s_mov_b32 {S('t0')}, 0")
+            else:
+                self.i(f"s_lshl_b32 {S('t0')}, {ka('o_ss')}, 5")                   # strip B: 32 rows further
+            for k in range(8):
+                self.i(f"s_waitcnt lgkmcnt({7 - k})")
+                self.i(f"buffer_store_dwordx4 {vr(x[k], 4)}, {vr(gofs)}, {S('osrd')}, {S('t0')} offen")
+                if k < 7:
+                    self.i(f"s_add_u32 {S('t0')}, {S('t0')}, {S('t1')}")
+        self.i(f"v_mov_b32 {vr(V_PS1)}, 0")
+
+    # ---- the kernel --------------------------------------------------------------------------------------------------------------
+    def kernel(self):
+        n = self.name
+        self.L += [f"\t.globl\t{n}", "\t.p2align\t8", f"\t.type\t{n},@function", f"{n}:"]
+        self.i(f"s_load_dwordx16 s[{KBASE_SGPR}:{KBASE_SGPR + 15}], s[0:1], 0")
+        self.i(f"s_load_dwordx16 s[{KBASE_SGPR + 16}:{KBASE_SGPR + 31}], s[0:1], 64")
+        self.i(f"s_load_dwordx8 s[{KBASE_SGPR + 32}:{KBASE_SGPR + 39}], s[0:1], 128")
+        L, T0, T1, T2, T3 = vr(V_LANE), *(vr(x) for x in V_T)
+        W = S('wave')
+        self.i(f"v_and_b32 {L}, 63, v0")
+        self.i(f"v_lshrrev_b32 {T0}, 6, v0")
+        self.i("s_nop 0")
+        self.i(f"v_readfirstlane_b32 {W}, {T0}")
+        self.i("s_waitcnt lgkmcnt(0)")
+        # slot / xcd of this workgroup: xcd_mode ? (xcd = wg & 7, slot = wg >> 3) : (xcd = 0, slot = wg)
+        self.i(f"s_and_b32 {S('xcd')}, s2, 7")
+        self.i(f"s_lshr_b32 {S('slot')}, s2, 3")
+        self.i(f"s_cmp_eq_u32 {ka('xcd_mode')}, 0")
+        self.i(f"s_cselect_b32 {S('xcd')}, 0, {S('xcd')}")
+        self.i(f"s_cselect_b32 {S('slot')}, s2, {S('slot')}")
+        self.i(f"s_mul_i32 {S('Ux')}, {ka('hx')}, {ka('NU')}")
+        self.i(f"s_lshl_b32 {S('ktile')}, {ka('k_ss')}, 6")
+        self.i(f"s_lshl_b32 {S('vtile')}, {ka('v_ss')}, 6")
+        self.i(f"s_lshl_b32 {S('w4k')}, {W}, 12")
+        # constant descriptor words: records = bytes of one (batch, head) slab / of one item's rows, flags = raw buffer
+        for sr, ss, rows in (('ksrd', 'k_ss', 'Sk'), ('vsrd', 'v_ss', 'Sk'), ('qsrd_n', 'q_ss', None), ('osrd', 'o_ss', None)):
+            if rows:
+                self.i(f"s_sub_u32 {S('t0')}, {ka(rows)}, 1")
+                self.i(f"s_mul_i32 {S('t0')}, {S('t0')}, {ka(ss)}")
+            else:
+                self.i(f"s_mul_i32 {S('t0')}, {ka(ss)}, 255")
+            self.i(f"s_add_u32 {S(sr, 2)}, {S('t0')}, 256")
+            self.i(f"s_mov_b32 {S(sr, 3)}, 0x00020000")
+        self.i(f"s_mov_b32 {S('lsrd', 2)}, 1024")
+        self.i(f"s_mov_b32 {S('lsrd', 3)}, 0x00020000")
+        # -- lane constants
+        self.i(f"v_and_b32 {T0}, 31, {L}")                                        # r
+        self.i(f"v_lshrrev_b32 {T1}, 5, {L}")                                     # h
+        # koff[ks] = r*256 + (((2ks+h) ^ sw(r)) << 4), sw(r) = ((r&3)<<2) | ((r>>2)&3)  ==  base ^ (32 ks)
+        self.i(f"v_and_b32 {T2}, 3, {T0}")
+        self.i(f"v_lshlrev_b32 {T2}, 2, {T2}")
+        self.i(f"v_bfe_u32 {T3}, {T0}, 2, 2")
+        self.i(f"v_or_b32 {T2}, {T2}, {T3}")
+        self.i(f"v_xor_b32 {T2}, {T2}, {T1}")
+        self.i(f"v_lshlrev_b32 {T2}, 4, {T2}")
+        self.i(f"v_lshl_add_u32 {T2}, {T0}, 8, {T2}")
+        for ks in range(8):
+            self.i(f"v_xor_b32 {vr(KOFF(ks))}, {32 * ks}, {T2}")
+        # causal threshold tA = r + 1 - 4h
+        self.i(f"v_lshlrev_b32 {T2}, 2, {T1}")
+        self.i(f"v_sub_u32 {vr(V_TA)}, {T0}, {T2}")
+        self.i(f"v_add_u32 {vr(V_TA)}, 1, {vr(V_TA)}")
+        # voff[db][hi] = V_BASE + R*256 + ((ch ^ sw(R)) << 4) + 8 (tp&1);  R = 4h + tq + 8hi, ch = 4db + 2 g1 + (tp>>1),
+        # sw(R) = (tq << 2) | (h + 2 hi);  g1 = (lane>>4)&1, tq = (lane&15)>>2, tp = lane&3
+        e0, e1, e2, e3, e4 = (vr(x) for x in V_E[1:6])
+        self.i(f"v_bfe_u32 {e0}, {L}, 2, 2")                                      # tq
+        self.i(f"v_and_b32 {e1}, 3, {L}")                                         # tp
+        self.i(f"v_bfe_u32 {e2}, {L}, 4, 1")                                      # g1
+        self.i(f"v_lshrrev_b32 {e3}, 1, {e1}")
+        self.i(f"v_lshl_add_u32 {e3}, {e2}, 1, {e3}")                             # c2 = 2 g1 + (tp >> 1)
+        self.i(f"v_and_b32 {e1}, 1, {e1}")
+        self.i(f"v_lshlrev_b32 {e1}, 3, {e1}")                                    # 8 (tp & 1)
+        self.i(f"v_lshl_add_u32 {e4}, {T1}, 2, {e0}")                             # 4h + tq
+        for hi in range(2):
+            for db in range(4):
+                d = vr(VOFF(db, hi))
+                # ch ^ sw = ((db ^ tq) << 2) | (c2 ^ (h + 2 hi))
+                self.i(f"v_xor_b32 {T2}, {db}, {e0}")
+                self.i(f"v_add_u32 {T3}, {2 * hi}, {T1}")
+                self.i(f"v_xor_b32 {T3}, {T3}, {e3}")
+                self.i(f"v_lshl_add_u32 {T2}, {T2}, 2, {T3}")
+                self.i(f"v_lshlrev_b32 {T2}, 4, {T2}")
+                self.i(f"v_add_u32 {T3}, {8 * hi}, {e4}")                         # R
+                self.i(f"v_lshl_add_u32 {T2}, {T3}, 8, {T2}")
+                self.i(f"v_add_u32 {T2}, {T2}, {e1}")
+                self.i(f"v_add_u32 {d}, {V_BASE}, {T2}")
+        # DMA source offsets: row R = 16 wave + 4 t + q4 -> R * ss + ((c16 ^ ((q4 << 2) | t)) << 4) - 1024 t
+        self.i(f"v_lshrrev_b32 {e0}, 4, {L}")                                     # q4
+        self.i(f"v_and_b32 {e1}, 15, {L}")                                        # c16
+        self.i(f"s_lshl_b32 {S('t0')}, {W}, 4")
+        self.i(f"s_lshl_b32 {S('t1')}, {W}, 6")
+        for t in range(4):
+            self.i(f"v_lshl_or_b32 {e2}, {e0}, 2, {t}")
+            self.i(f"v_xor_b32 {e2}, {e2}, {e1}")
+            self.i(f"v_lshlrev_b32 {e2}, 4, {e2}")
+            self.i(f"v_add_u32 {e3}, {4 * t}, {e0}")
+            self.i(f"v_add_u32 {e3}, {S('t0')}, {e3}")                            # R
+            for d, ss in ((KDOFF(t), 'k_ss'), (VDOFF(t), 'v_ss')):
+                self.i(f"v_mul_lo_u32 {e4}, {e3}, {ka(ss)}")
+                self.i(f"v_add_u32 {e4}, {e4}, {e2}")
+                self.i(f"v_subrev_u32 {vr(d)}, {1024 * t}, {e4}")
+            # Q: row-in-16 = 4 t + q4 -> (64 wave + 4t + q4) * q_ss + ((c16 ^ (4t + q4)) << 4) - 1024 t
+            self.i(f"v_add_u32 {e3}, {4 * t}, {e0}")
+            self.i(f"v_xor_b32 {e2}, {e3}, {e1}")
+            self.i(f"v_lshlrev_b32 {e2}, 4, {e2}")
+            self.i(f"v_add_u32 {e3}, {S('t1')}, {e3}")                            # + the wave's first row of the block (64 wave)
+            self.i(f"v_mul_lo_u32 {e4}, {e3}, {ka('q_ss')}")
+            self.i(f"v_add_u32 {e4}, {e4}, {e2}")
+            self.i(f"v_subrev_u32 {vr(QDOFF(t))}, {1024 * t}, {e4}")
+        # -- first item: decode, fetch its Q block, K0, then V0 and K1
+        self.i(f"s_mov_b32 {S('n_u')}, 0")
+        self.i(f"s_mov_b32 {S('n_sub')}, 0")
+        self.decode()
+        lend = f".L{n}_end"
+        self.i(f"s_cmp_eq_u32 {S('n_valid')}, 0")
+        self.i(f"s_cbranch_scc1 {lend}")
+        self.i(f"s_lshl_b32 {S('qdst')}, {S('w4k')}, 2")
+        self.i(f"s_add_u32 {S('qdst')}, {S('qdst')}, {Q_BASE}")
+        self.i(f"s_mov_b32 {S('qoff')}, 0")
+        self.i(f"s_mov_b32 {S('qrem')}, 4")
+        for g in range(4):
+            self.q_group()
+        self.i(f"s_mov_b64 {S('ksrd', 0, 2)}, {S('ksrd_n')}")
+        self.i(f"s_mov_b64 {S('vsrd', 0, 2)}, {S('vsrd_n')}")
+        self.i(f"s_mov_b32 {S('koff')}, 0")
+        self.i(f"s_mov_b32 {S('voff')}, 0")
+        self.i(self.setm0('k', 0))
+        self.i("s_nop 0")
+        for t in range(4):
+            self.i(self.dma('K', t))
+        self.i(self.setm0('v', 0))
+        self.i("s_nop 0")
+        for t in range(4):
+            self.i(self.dma('V', t))
+        self.i(f"s_add_u32 {S('koff')}, {S('koff')}, {S('ktile')}")
+        self.i(self.setm0('k', 1))
+        self.i("s_nop 0")
+        for t in range(4):
+            self.i(self.dma('K', t))
+        self.i(f"s_add_u32 {S('koff')}, {S('koff')}, {S('ktile')}")               # next K piece: tile 2
+        self.i(f"s_add_u32 {S('voff')}, {S('voff')}, {S('vtile')}")               # next V piece: tile 1
+        self.i("s_waitcnt vmcnt(8)")                                              # Q and K0 (V0, K1 are the eight youngest)
+        self.i("s_barrier")
+        litem = f".L{n}_item"
+        self.lab(litem)
+        # ---- item switch: the decoded item becomes current; decode the one after it ----------------------------------------------------
+        self.i(f"s_mov_b32 {S('irem')}, {S('n_nt')}")
+        self.i(f"s_sub_u32 {S('krem')}, {S('n_nt')}, 2")
+        self.i(f"s_sub_u32 {S('vrem')}, {S('n_nt')}, 1")
+        if self.causal:
+            self.i(f"s_add_u32 {S('wrem')}, {S('n_nt')}, {W}")
+            self.i(f"s_sub_u32 {S('wrem')}, {S('wrem')}, 4")                      # wnt - 1 = nt - 4 + wave
+        else:
+            self.i(f"s_sub_u32 {S('wrem')}, {S('n_nt')}, 1")
+        self.make_out_srds()
+        if self.causal:
+            self.i(f"s_xor_b32 {S('n_sub')}, {S('n_sub')}, 1")
+            self.i(f"s_cmp_eq_u32 {S('n_sub')}, 0")
+            self.i(f"s_cselect_b32 {S('t0')}, 1, 0")
+            self.i(f"s_add_u32 {S('n_u')}, {S('n_u')}, {S('t0')}")
+        else:
+            self.i(f"s_add_u32 {S('n_u')}, {S('n_u')}, 1")
+        self.decode()
+        self.i(f"s_mov_b32 {S('nt_n')}, {S('n_nt')}")
+        self.i(f"s_lshl_b32 {S('qrem')}, {S('n_valid')}, 2")                      # 4 groups of Q pieces if there is a next item
+        self.i(f"s_lshl_b32 {S('qdst')}, {S('w4k')}, 2")
+        self.i(f"s_add_u32 {S('qdst')}, {S('qdst')}, {Q_BASE}")
+        self.i(f"s_mov_b32 {S('qoff')}, 0")
+        self.item_prologue()
+        self.i("s_waitcnt vmcnt(0)")
+        self.i("s_barrier")                    # V0 / K1 published; every wave is done with K slot 0
+        # ---- tile loop, unrolled by the two S buffers ----------------------------------------------------------------------------------
+        lloop = f".L{n}_loop"
+        self.lab(lloop)
+        for p in (0, 1):
+            lnf, ll, ld = (self.ul(x) for x in ("notfull", "last", "done"))
+            self.stream_top()
+            self.i(f"s_cmp_gt_i32 {S('wrem')}, 0")
+            self.i(f"s_cbranch_scc0 {lnf}")
+            self.body_full(p)
+            self.lab(ld)
+            self.stream_bottom()
+            self.out_of_line(True)
+            self.lab(lnf)
+            self.i(f"s_cmp_eq_u32 {S('wrem')}, 0")
+            self.i(f"s_cbranch_scc1 {ll}")
+            self.body_skip(p)
+            self.i(f"s_branch {ld}")
+            self.lab(ll)
+            self.body_last(p)
+            self.i(f"s_branch {ld}")
+            self.out_of_line(False)
+        self.i(f"s_sub_u32 {S('irem')}, {S('irem')}, 2")
+        self.i(f"s_cmp_gt_i32 {S('irem')}, 0")
+        self.i(f"s_cbranch_scc1 {lloop}")
+        self.item_epilogue()
+        self.i(f"s_cmp_lg_u32 {S('n_valid')}, 0")
+        self.i(f"s_cbranch_scc1 {litem}")
+        self.lab(lend)
+        self.i("s_endpgm")
+        self.main += self.ool
+        self.main += [f".L{n}_fend:", f"\t.size\t{n}, .L{n}_fend-{n}"]
+
+    def descriptor(self):
+        n = self.name
+        return f"""
+	.section	.rodata,"a",@progbits
+	.p2align	6, 0x0
+	.amdhsa_kernel {n}
+		.amdhsa_group_segment_fixed_size {LDS_BYTES}
+		.amdhsa_private_segment_fixed_size 0
+		.amdhsa_kernarg_size {4 * KARG_DWORDS}
+		.amdhsa_user_sgpr_count 2
+		.amdhsa_user_sgpr_kernarg_segment_ptr 1
+		.amdhsa_system_sgpr_workgroup_id_x 1
+		.amdhsa_system_sgpr_workgroup_id_y 0
+		.amdhsa_system_sgpr_workgroup_id_z 0
+		.amdhsa_system_vgpr_workitem_id 0
+		.amdhsa_next_free_vgpr 512
+		.amdhsa_next_free_sgpr {KBASE_SGPR + KARG_DWORDS}
+		.amdhsa_accum_offset 256
+		.amdhsa_reserve_vcc 1
+		.amdhsa_float_round_mode_32 0
+		.amdhsa_float_round_mode_16_64 0
+		.amdhsa_float_denorm_mode_32 3
+		.amdhsa_float_denorm_mode_16_64 3
+		.amdhsa_dx10_clamp 1
+		.amdhsa_ieee_mode 1
+		.amdhsa_fp16_overflow 0
+		.amdhsa_tg_split 0
+	.end_amdhsa_kernel
+	.text
+"""
+
+    def metadata(self):
+        n = self.name
+        return f"""  - .agpr_count:     256
+    .args:
+      - .offset:         0
+        .size:           {4 * KARG_DWORDS}
+        .value_kind:     by_value
+    .group_segment_fixed_size: {LDS_BYTES}
+    .kernarg_segment_align: 8
+    .kernarg_segment_size: {4 * KARG_DWORDS}
+    .max_flat_workgroup_size: 256
+    .name:           {n}
+    .private_segment_fixed_size: 0
+    .sgpr_count:     {KBASE_SGPR + KARG_DWORDS + 6}
+    .sgpr_spill_count: 0
+    .symbol:         {n}.kd
+    .uniform_work_group_size: 1
+    .uses_dynamic_stack: false
+    .vgpr_count:     512
+    .vgpr_spill_count: 0
+    .wavefront_size: 64
+"""
+
+
+def kernels():
+    return [(dt, causal) for dt in ("bf16", "fp16") for causal in (True, False)]
+
+
+def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--offsets":       # the kernarg layout as a C header fragment (pfa_p4.hip static_asserts it)
+        for k, v in KA.items():
+            print(f"#define P4_KA_{k.upper()} {4 * v}")
+        print(f"#define P4_KARG_BYTES {4 * KARG_DWORDS}")
+        print(f"#define P4_LDS_BYTES {LDS_BYTES}")
+        return
+    out = ['\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', "\t.amdhsa_code_object_version 6", "\t.text"]
+    meta = []
+    for dt, causal in kernels():
+        g = Gen(dt, causal)
+        g.kernel()
+        out += g.main
+        out.append(g.descriptor())
+        meta.append(g.metadata())
+    out.append("\t.amdgpu_metadata\n---\namdhsa.kernels:\n" + "".join(meta) +
+               "amdhsa.target:   amdgcn-amd-amdhsa--gfx950\namdhsa.version:\n  - 1\n  - 2\n...\n\t.end_amdgpu_metadata")
+    sys.stdout.write("\n".join(out) + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -9,9 +9,12 @@
 #include <string.h>
 
 #include "fa3_fwd_kernel.h"
+#ifdef PFA_DEV_VARIANTS      // development build only (make DEV=1): schedule experiments and timing-only ablations, see pick()
 #include "fa3_fwd_pipe_kernel.h"
 #include "fa3_fwd_stagger_kernel.h"
+#endif
 #include "fa3_weights_kernel.h"
+#include "pfa_p4.h"
 
 namespace pfa { const void* w4_kernel(int dtype, bool causal, bool out32); }   // pfa_w4.hip
 
@@ -27,14 +30,19 @@ struct Variant {
     int nthreads;
     int block_m;
     int xcd_group = 0;
+    bool p4 = false;       // the persistent assembly kernel (pfa_p4.hip): launched through its own module, fn unused
+    int p4_grid = 0;
 };
 
 template <typename T, int D, bool C, bool S, bool K, int VAR, typename OT>
 Variant mk(const char* tn, const char* on) {
     Variant v;
+#ifdef PFA_DEV_VARIANTS
     if constexpr (VAR & pfa::VAR_STAGGER) v.fn = (const void*)&pfa::fa3_fwd_stagger_kernel<T, D, C, S, K, VAR, OT>;
     else if constexpr (VAR & pfa::VAR_PIPE) v.fn = (const void*)&pfa::fa3_fwd_pipe_kernel<T, D, C, S, K, VAR, OT>;
-    else v.fn = (const void*)&pfa::fa3_fwd_kernel<T, D, C, S, K, VAR, OT>;
+    else
+#endif
+        v.fn = (const void*)&pfa::fa3_fwd_kernel<T, D, C, S, K, VAR, OT>;
     snprintf(v.name, sizeof(v.name), "fa3_fwd_%s_d%d_%s%s%s_%s_v%d", tn, D, C ? "causal" : "full", S ? "_splitp" : "",
              K ? "_kmask" : "", on, VAR);
     v.lds_bytes = ((VAR & pfa::VAR_STAGE2) ? 4 : 2) * 2 * pfa::BLOCK_N * D * 2;
@@ -67,11 +75,26 @@ Variant by_d(int D, bool causal, bool split, bool kmask, bool out32, const char*
     return D == 128 ? by_causal<T, 128>(causal, split, kmask, out32, tn) : by_causal<T, 64>(causal, split, kmask, out32, tn);
 }
 
+#ifdef PFA_DEV_VARIANTS
 // Experimental variants (A/B only): bf16, D=128, single-P, bf16 store; selected by flags bits 8..15.
 template <int VAR>
 Variant exp_variant(bool causal) {
     return causal ? mk<__bf16, 128, true, false, false, VAR, __bf16>("bf16", "o16")
                   : mk<__bf16, 128, false, false, false, VAR, __bf16>("bf16", "o16");
+}
+#endif
+
+// persistent 4 waves x 64 rows in assembly (gen_fa3_fwd_p4.py / pfa_p4.hip)
+Variant p4_variant(const pfa_fa3_args* a, bool causal) {
+    Variant v;
+    v.fn = nullptr;
+    snprintf(v.name, sizeof(v.name), "fa3_fwd_p4_%s_d128_%s_o16", a->dtype_in == PFA_DTYPE_BF16 ? "bf16" : "fp16", causal ? "causal" : "full");
+    v.p4 = true;
+    v.p4_grid = pfa::p4_workgroups(a);
+    v.lds_bytes = 0;
+    v.nthreads = 256;
+    v.block_m = 256;
+    return v;
 }
 
 // 4 waves x 64 rows (fa3_fwd_w4_kernel.h): D = 128, single P, no element mask
@@ -102,12 +125,21 @@ Variant pick(const pfa_fa3_args* a) {
     // below: S512 +1 %, S1Kc -6 %, S512c -6 %, S256 -5 %).  Variant 43 forces it, 44 forces the 8-wave kernel (A/B).
     const bool w4_ok = a->D == 128 && !split && !kmask && (int64_t)a->B * a->H * a->H < (1ll << 32);   // last: its multiply-high head index
     const int64_t avg_tiles = (causal ? (int64_t)a->Sk / 2 : (int64_t)a->Sk) / pfa::BLOCK_N;
+    // Production selectors (A/B and tests): 43 = the 4-wave HIP kernel, 44 = the 8-wave kernel, 45 = the persistent assembly kernel.
+    // The persistent kernel takes the long aligned problems (pfa::p4_eligible), the 4-wave HIP kernel the other long ones.
+    if (pfa::p4_eligible(a) && (var == 45 || (var == 0 && avg_tiles >= 16))) {
+        Variant v = p4_variant(a, causal);
+        if (v.p4_grid > 0) return v;           // (0: the code object did not load on this device -- fall through to the HIP kernels)
+    }
+#ifdef PFA_DEV_VARIANTS
     if (w4_ok && (var == 47 || var == 48 || var == 49)) {      // A/B: head-grouped block order 2 / 4 / off
         Variant v = w4_variant(a, causal, out32);
         v.xcd_group = var == 47 ? 2 : (var == 48 ? 4 : 0);
         return v;
     }
-    if (w4_ok && (var == 43 || (var == 0 && avg_tiles >= 16))) return w4_variant(a, causal, out32);
+#endif
+    if (w4_ok && (var == 43 || ((var == 0 || var == 45) && avg_tiles >= 16))) return w4_variant(a, causal, out32);
+#ifdef PFA_DEV_VARIANTS
     if (var != 0 && var != 44 && a->dtype_in == PFA_DTYPE_BF16 && a->D == 128 && !split && !kmask && !out32) {
         switch (var) {
             case 1: return exp_variant<pfa::VAR_SCHED | pfa::VAR_GLDS | pfa::VAR_BUFDMA>(causal);          // exact lazy rescale (no defer-max)
@@ -156,6 +188,7 @@ Variant pick(const pfa_fa3_args* a) {
             default: break;
         }
     }
+#endif
     return a->dtype_in == PFA_DTYPE_BF16 ? by_d<__bf16>(a->D, causal, split, kmask, out32, "bf16")
                                          : by_d<_Float16>(a->D, causal, split, kmask, out32, "fp16");
 }
@@ -167,6 +200,12 @@ int check(const pfa_fa3_args* a) {
     if (!a) return PFA_ERR_NULL;
     if (a->size != sizeof(pfa_fa3_args)) return PFA_ERR_STRUCT_SIZE;
     if (a->flags & ~(PFA_FLAG_SPLIT_P | PFA_FLAG_NO_XCD_MAP | PFA_FLAG_VARIANT_MASK)) return PFA_ERR_FLAGS;
+#ifndef PFA_DEV_VARIANTS
+    {   // the production library knows three kernel selectors (43 / 44 / 45, see pick()); development variants need make DEV=1
+        const unsigned var = (a->flags & PFA_FLAG_VARIANT_MASK) >> 8;
+        if (var != 0 && var != 43 && var != 44 && var != 45) return PFA_ERR_FLAGS;
+    }
+#endif
     if (!a->q || !a->k || !a->v || !a->o) return PFA_ERR_NULL;
     if (a->key_mask && a->mask) return PFA_ERR_FLAGS;
     if (a->kv_group < 0 || a->reserved0 != 0 || (a->kv_group > 1 && a->H % a->kv_group != 0)) return PFA_ERR_SHAPE;
@@ -291,6 +330,7 @@ int pfa_fa3_describe(const pfa_fa3_args* a, char* buf, size_t n) {
         strncpy(buf, v.name, n - 1);
         buf[n - 1] = 0;
     }
+    if (v.p4) return v.p4_grid;
     const int nq = (a->Sq + v.block_m - 1) / v.block_m;
     return nq * a->B * a->H;
 }
@@ -319,6 +359,12 @@ int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream) {
     p.mbits = use_mbits ? (const unsigned long long*)a->workspace : nullptr;
     p.mb_sb = mb.ob; p.mb_sh = mb.oh; p.mb_sq = mb.oq;
     const Variant v = pick(a);
+    if (v.p4) {
+        int herr = 0;
+        const int st4 = pfa::p4_launch(a, stream, &herr);
+        if (st4 != PFA_OK) g_last_hip_error = herr;
+        return st4;
+    }
     p.nqblk = (a->Sq + v.block_m - 1) / v.block_m;
     p.kv_group = a->kv_group > 1 ? a->kv_group : 1;
     p.xcd_group = v.xcd_group;

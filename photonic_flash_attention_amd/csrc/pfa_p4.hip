@@ -1,0 +1,174 @@
+// pfa_p4.hip -- host side of the persistent 4-wave forward (gen_fa3_fwd_p4.py): the kernel is gfx950 assembly assembled into a code
+// object of its own (build/fa3_fwd_p4.hsaco), embedded here byte for byte and loaded once per device with hipModuleLoadData.
+// The only process-wide state of the library: the per-device module handles, filled under a mutex and never changed afterwards.
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "pfa_hip.h"
+#include "pfa_p4.h"
+#include "build/fa3_fwd_p4_offsets.h"          // generated: P4_KA_* byte offsets of the kernarg block, P4_LDS_BYTES
+
+// the code object, embedded by the assembler
+__asm__(".section .rodata\n"
+        ".global pfa_p4_hsaco_begin\n.global pfa_p4_hsaco_end\n"
+        ".balign 4096\n"
+        "pfa_p4_hsaco_begin:\n"
+        ".incbin \"" PFA_P4_HSACO_PATH "\"\n"
+        "pfa_p4_hsaco_end:\n"
+        ".byte 0\n"
+        ".previous\n");
+extern "C" const unsigned char pfa_p4_hsaco_begin[];
+extern "C" const unsigned char pfa_p4_hsaco_end[];
+
+namespace pfa {
+
+// kernarg block of fa3_fwd_p4_* (gen_fa3_fwd_p4.py `KA`); byte strides are 32-bit (the host refuses anything larger)
+struct P4Params {
+    const void* q;
+    const void* k;
+    const void* v;
+    void* o;
+    float* lse;
+    uint32_t q_sb, q_sh, k_sb, k_sh, v_sb, v_sh, o_sb, o_sh;
+    uint32_t q_ss, k_ss, v_ss, o_ss;
+    uint32_t H, Sq, Sk, NB, NU, magic_NU, magic_H, kv_group, magic_G;
+    float scale_log2, thr;
+    uint32_t hx, xcd_mode, SL, nt_full, pad;
+    unsigned long long* dbg;
+};
+#define P4_CHECK(field, macro) static_assert(offsetof(P4Params, field) == macro, "kernarg layout of " #field)
+P4_CHECK(q, P4_KA_Q); P4_CHECK(k, P4_KA_K); P4_CHECK(v, P4_KA_V); P4_CHECK(o, P4_KA_O); P4_CHECK(lse, P4_KA_LSE);
+P4_CHECK(q_sb, P4_KA_Q_SB); P4_CHECK(q_sh, P4_KA_Q_SH); P4_CHECK(k_sb, P4_KA_K_SB); P4_CHECK(k_sh, P4_KA_K_SH);
+P4_CHECK(v_sb, P4_KA_V_SB); P4_CHECK(v_sh, P4_KA_V_SH); P4_CHECK(o_sb, P4_KA_O_SB); P4_CHECK(o_sh, P4_KA_O_SH);
+P4_CHECK(q_ss, P4_KA_Q_SS); P4_CHECK(k_ss, P4_KA_K_SS); P4_CHECK(v_ss, P4_KA_V_SS); P4_CHECK(o_ss, P4_KA_O_SS);
+P4_CHECK(H, P4_KA_H); P4_CHECK(Sq, P4_KA_SQ); P4_CHECK(Sk, P4_KA_SK); P4_CHECK(NB, P4_KA_NB); P4_CHECK(NU, P4_KA_NU);
+P4_CHECK(magic_NU, P4_KA_MAGIC_NU); P4_CHECK(magic_H, P4_KA_MAGIC_H); P4_CHECK(kv_group, P4_KA_KV_GROUP);
+P4_CHECK(magic_G, P4_KA_MAGIC_G); P4_CHECK(scale_log2, P4_KA_SCALE_LOG2); P4_CHECK(thr, P4_KA_THR); P4_CHECK(hx, P4_KA_HX);
+P4_CHECK(xcd_mode, P4_KA_XCD_MODE); P4_CHECK(SL, P4_KA_SL); P4_CHECK(nt_full, P4_KA_NT_FULL); P4_CHECK(dbg, P4_KA_DBG);
+static_assert(sizeof(P4Params) == P4_KARG_BYTES, "kernarg size");
+
+namespace {
+constexpr int MAX_DEV = 64;
+struct DevMod {
+    hipModule_t mod = nullptr;
+    hipFunction_t fn[2][2] = {};     // [dtype][causal]
+    int n_cu = 0;
+    int state = 0;                   // 0 = not tried, 1 = ready, -1 = failed
+};
+DevMod g_mod[MAX_DEV];
+std::mutex g_mu;
+
+uint32_t magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / d) + 1u; }   // n / d == mulhi(n, magic) while n * d < 2^32
+
+const DevMod* module_for(int dev) {
+    if (dev < 0 || dev >= MAX_DEV) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    DevMod& m = g_mod[dev];
+    if (m.state == 0) {
+        m.state = -1;
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        struct Restore {       // the module belongs to the device that is current while it is loaded
+            int cur, dev;
+            Restore(int c, int d) : cur(c), dev(d) { if (c != d) (void)hipSetDevice(d); }
+            ~Restore() { if (cur != dev) (void)hipSetDevice(cur); }
+        } restore(cur, dev);
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        m.n_cu = prop.multiProcessorCount;
+        if (hipModuleLoadData(&m.mod, pfa_p4_hsaco_begin) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        static const char* names[2][2] = {{"fa3_fwd_p4_bf16_full_o16", "fa3_fwd_p4_bf16_causal_o16"},
+                                          {"fa3_fwd_p4_fp16_full_o16", "fa3_fwd_p4_fp16_causal_o16"}};
+        for (int d = 0; d < 2; ++d)
+            for (int c = 0; c < 2; ++c)
+                if (hipModuleGetFunction(&m.fn[d][c], m.mod, names[d][c]) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        m.state = 1;
+    }
+    return m.state == 1 ? &m : nullptr;
+}
+
+bool fits_u32(int64_t x) { return x >= 0 && x <= 0xffffffffLL; }
+}  // namespace
+
+// Shapes the persistent kernel takes (everything else stays on the HIP kernels): D = 128, one P operand, 16-bit store, no mask /
+// seqlens, whole 256-row Q blocks and an even number of 64-key tiles (the two S buffers alternate from tile 0 of every item), at
+// least 4 tiles; under the causal mask Sq == Sk and an even number of Q blocks (units are heavy + light block pairs).
+bool p4_eligible(const pfa_fa3_args* a) {
+    if (a->D != 128 || (a->flags & PFA_FLAG_SPLIT_P) || a->dtype_out != a->dtype_in) return false;
+    if (a->key_mask || a->mask || a->seqlens_k) return false;
+    if (a->Sq % 256 != 0 || a->Sk % 128 != 0 || a->Sk < 256) return false;
+    if (a->causal && (a->Sq != a->Sk || (a->Sq / 256) % 2 != 0)) return false;
+    const int64_t st[] = {a->q_stride_b, a->q_stride_h, a->q_stride_s, a->k_stride_b, a->k_stride_h, a->k_stride_s,
+                          a->v_stride_b, a->v_stride_h, a->v_stride_s, a->o_stride_b, a->o_stride_h, a->o_stride_s};
+    for (int64_t s : st)
+        if (!fits_u32(s * 2)) return false;
+    // row strides: a wave's DMA offsets (row * stride + 256) and an item's output rows stay below 2^31; rows at least 256 B apart
+    if (a->q_stride_s < 128 || a->k_stride_s < 128 || a->v_stride_s < 128 || a->o_stride_s < 128) return false;
+    if ((int64_t)a->Sk * a->k_stride_s * 2 > 0x7fffffffLL || (int64_t)a->Sk * a->v_stride_s * 2 > 0x7fffffffLL) return false;
+    if (256 * a->q_stride_s * 2 > 0x7fffffffLL || 256 * a->o_stride_s * 2 > 0x7fffffffLL) return false;
+    if ((a->o_stride_s * 2) % 16 != 0 || (reinterpret_cast<uintptr_t>(a->o) & 15u)) return false;      // 16-byte row stores
+    const int64_t BH = (int64_t)a->B * a->H, NB = a->Sq / 256, NU = a->causal ? NB / 2 : NB;
+    if (BH * NU > (1ll << 24) || BH * a->H >= (1ll << 32)) return false;                                 // multiply-high ranges
+    return true;
+}
+
+int p4_workgroups(const pfa_fa3_args* a) {
+    const DevMod* m = module_for(a->device_id);
+    if (!m) return 0;
+    const int BH = a->B * a->H;
+    return BH % 8 == 0 ? (m->n_cu / 8) * 8 : m->n_cu;
+}
+
+// Enqueue.  Returns PFA_OK, or PFA_ERR_LAUNCH / PFA_ERR_DEVICE (hip error in *hip_err).
+int p4_launch(const pfa_fa3_args* a, void* stream, int* hip_err) {
+    const DevMod* m = module_for(a->device_id);
+    if (!m) return PFA_ERR_DEVICE;
+    P4Params p;
+    memset(&p, 0, sizeof(p));
+    p.q = a->q; p.k = a->k; p.v = a->v; p.o = a->o; p.lse = a->lse;
+    p.q_sb = (uint32_t)(a->q_stride_b * 2); p.q_sh = (uint32_t)(a->q_stride_h * 2); p.q_ss = (uint32_t)(a->q_stride_s * 2);
+    p.k_sb = (uint32_t)(a->k_stride_b * 2); p.k_sh = (uint32_t)(a->k_stride_h * 2); p.k_ss = (uint32_t)(a->k_stride_s * 2);
+    p.v_sb = (uint32_t)(a->v_stride_b * 2); p.v_sh = (uint32_t)(a->v_stride_h * 2); p.v_ss = (uint32_t)(a->v_stride_s * 2);
+    p.o_sb = (uint32_t)(a->o_stride_b * 2); p.o_sh = (uint32_t)(a->o_stride_h * 2); p.o_ss = (uint32_t)(a->o_stride_s * 2);
+    p.H = (uint32_t)a->H; p.Sq = (uint32_t)a->Sq; p.Sk = (uint32_t)a->Sk;
+    p.NB = (uint32_t)(a->Sq / 256);
+    p.NU = a->causal ? p.NB / 2 : p.NB;
+    p.magic_NU = magic(p.NU); p.magic_H = magic(p.H);
+    p.kv_group = a->kv_group > 1 ? (uint32_t)a->kv_group : 1u;
+    p.magic_G = magic(p.kv_group);
+    p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
+    p.thr = 8.0f / p.scale_log2;
+    const int BH = a->B * a->H;
+    const int grid = p4_workgroups(a);
+    p.xcd_mode = BH % 8 == 0 ? 1u : 0u;
+    p.hx = p.xcd_mode ? (uint32_t)(BH / 8) : (uint32_t)BH;
+    p.SL = p.xcd_mode ? (uint32_t)(grid / 8) : (uint32_t)grid;
+    p.nt_full = (uint32_t)(a->Sk / 64);
+    p.dbg = nullptr;
+
+    size_t sz = sizeof(p);
+    void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+    hipFunction_t fn = m->fn[a->dtype_in == PFA_DTYPE_BF16 ? 0 : 1][a->causal ? 1 : 0];
+    int prev = -1;
+    hipError_t e = hipGetDevice(&prev);
+    if (e == hipSuccess && prev != a->device_id) e = hipSetDevice(a->device_id);
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = (int)e;
+        (void)hipGetLastError();
+        return PFA_ERR_DEVICE;
+    }
+    e = hipModuleLaunchKernel(fn, (unsigned)grid, 1, 1, 256, 1, 1, 0, (hipStream_t)stream, nullptr, config);
+    if (prev != a->device_id) (void)hipSetDevice(prev);
+    if (e != hipSuccess) {
+        if (hip_err) *hip_err = (int)e;
+        (void)hipGetLastError();
+        return PFA_ERR_LAUNCH;
+    }
+    return PFA_OK;
+}
+
+}  // namespace pfa

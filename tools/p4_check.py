@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Persistent assembly forward (selector 45) against the 8-wave HIP kernel (44) and the 4-wave HIP kernel (43): outputs, LSE,
+then interleaved timing.  Run on the GPU box:  timeout -k 10 300 python3 tools/p4_check.py [--time]"""
+import argparse, os, statistics, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from photonic_flash_attention_amd import ops, _capi
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--time", action="store_true")
+ap.add_argument("--shapes", default="small")
+ap.add_argument("--dtype", default="bf16")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
+SHAPES = {
+    "small": [(1, 8, 512, True), (1, 8, 256, False), (1, 8, 512, False), (2, 4, 1024, True), (1, 3, 512, True), (3, 5, 768, False),
+              (1, 16, 2048, True), (2, 16, 1024, False)],
+    "big": [(4, 16, 4096, True), (4, 16, 4096, False), (1, 32, 16384, True), (16, 16, 2048, False)],
+}
+bad = 0
+for (B, H, S, causal) in SHAPES[a.shapes]:
+    g = torch.Generator(device=dev).manual_seed(B * 1000 + H * 10 + S)
+    q, k, v = (torch.randn(B, S, H, 128, device=dev, dtype=torch.float32, generator=g).to(dt) for _ in range(3))
+    qv, kv, vv = (t.permute(0, 2, 1, 3) for t in (q, k, v))
+    res = {}
+    for var in (44, 45):
+        out = torch.full((B, S, H, 128), float("nan"), device=dev, dtype=dt).permute(0, 2, 1, 3)
+        o, lse = ops.fa3_forward(qv, kv, vv, causal=causal, out=out, return_lse=True, _variant=var)
+        torch.cuda.synchronize()
+        res[var] = (o.float().clone(), lse.clone())
+    name = _capi.describe(ops.build_args(qv, kv, vv, out, causal=causal, variant=45)[0])
+    d_o = (res[45][0] - res[44][0]).abs()
+    d_l = (res[45][1] - res[44][1]).abs()
+    nan_o = int(torch.isnan(res[45][0]).sum())
+    mo, ml = float(d_o.nan_to_num(1e9).max()), float(d_l.nan_to_num(1e9).max())
+    ok = nan_o == 0 and mo <= 2e-2 and ml <= 1e-4
+    bad += 0 if ok else 1
+    print(f"B{B} H{H} S{S} {'causal' if causal else 'full  '} {name[0]} wg={name[1]}: max|dO| {mo:.3e}  max|dLSE| {ml:.3e}  nan {nan_o}  "
+          f"frac(dO>1e-2) {float((d_o > 1e-2).float().mean()):.2e}  {'ok' if ok else 'MISMATCH'}", flush=True)
+    if not ok:
+        # where: per (b, h, 64-row block) max error
+        e = d_o.nan_to_num(1e9).amax(dim=-1)             # [B,H,S]
+        eb = e.view(B, H, S // 64, 64).amax(dim=-1)
+        idx = (eb > 2e-2).nonzero()[:12]
+        print("   first bad (b, h, 64-row block):", idx.tolist(), flush=True)
+print("FAILED" if bad else "ALL OK", flush=True)
+if a.time and not bad:
+    for (B, H, S, causal) in SHAPES["big"]:
+        q, k, v = (torch.randn(B, S, H, 128, device=dev, dtype=torch.float32).to(dt) for _ in range(3))
+        qv, kv, vv = (t.permute(0, 2, 1, 3) for t in (q, k, v))
+        out = torch.empty(B, S, H, 128, device=dev, dtype=dt).permute(0, 2, 1, 3)
+        fl = 4.0 * B * H * S * S * 128 / (2 if causal else 1)
+        times = {43: [], 45: []}
+        for var in times:
+            for _ in range(20):
+                ops.fa3_forward(qv, kv, vv, causal=causal, out=out, _variant=var)
+        torch.cuda.synchronize()
+        for r in range(7):
+            for var in times:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    ops.fa3_forward(qv, kv, vv, causal=causal, out=out, _variant=var)
+                e1.record(); torch.cuda.synchronize()
+                times[var].append(e0.elapsed_time(e1) / 20)
+        for var in times:
+            med = statistics.median(times[var])
+            print(f"B{B} H{H} S{S} {'causal' if causal else 'full'} var {var}: {med:.4f} ms {fl / med / 1e9:.1f} TF", flush=True)
+sys.exit(1 if bad else 0)
