@@ -23,6 +23,7 @@ Register plan (per wave, 512 registers):
     v[16:143] S, double buffered: buf0 A, buf0 B, buf1 A, buf1 B (32 each: key block 0, key block 1)
     v[144:175] P (packed bf16) of A / B, v[176:191] K fragment ring, v[192:207] V^T fragment ring, v[208:] addresses and state
 """
+import os
 import sys
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -84,8 +85,9 @@ def PD(X, i):
     return 144 + (0 if X == 'A' else 16) + i
 
 
-KFR = lambda i: 176 + 4 * (i % 4)
-VFR = lambda i: 192 + 4 * (i % 4)
+RING = int(os.environ.get("P4_RING", "8"))          # K / V^T fragment rings: 4 (VGPRs) or 8 (the spare accumulator registers a[192:255])
+KFR = lambda i: (192 + 4 * (i % 8)) if RING == 8 else (176 + 4 * (i % 4))
+VFR = lambda i: (224 + 4 * (i % 8)) if RING == 8 else (192 + 4 * (i % 4))
 KOFF = lambda ks: 208 + ks
 VOFF = lambda db, hi: 216 + 2 * db + hi
 KDOFF = lambda t: 224 + t
@@ -106,6 +108,12 @@ V_LANE = 255
 V_E = list(range(0, 16))   # prologue / epilogue / rescale scratch (v0 = workitem id at entry)
 OA = lambda X, db, e=0: (0 if X == 'A' else 64) + 16 * db + e
 QA = lambda X, ks: 128 + (0 if X == 'A' else 32) + 4 * ks
+import os
+STAMP = int(os.environ.get("P4_STAMP", "0"))      # 1: every phase; 2: one stamp per iteration only (buckets 0 / 1 stay empty)
+ABL = os.environ.get("P4_ABL", "")                                         # timing-only ablations, see dma_plan
+DMA_PRICE = int(os.environ.get("P4_DMA_PRICE", "30"))                      # issue cycles budgeted for one LDS-DMA piece
+DMA_GAPS_V = [int(x) for x in os.environ.get("P4_DMA_GAPS_V", "1,5,9,13").split(",")]      # QK^T gaps that carry the V(j+1) pieces
+DMA_GAPS_K = [int(x) for x in os.environ.get("P4_DMA_GAPS_K", "17,21,25,27").split(",")]   # ... and the K(j+2) pieces
 NEG_BIG = "0xf149f2ca"     # -1e30f
 NEG_INF = "0xff800000"
 
@@ -116,6 +124,10 @@ def vr(base, n=1):
 
 def ar(base, n=1):
     return f"a{base}" if n == 1 else f"a[{base}:{base + n - 1}]"
+
+
+def fr(base, n):            # a fragment-ring register range: accumulator file when the rings are 8 deep
+    return ar(base, n) if RING == 8 else vr(base, n)
 
 
 class Lgkm:
@@ -145,10 +157,20 @@ class Gen:
         self.name = f"fa3_fwd_p4_{dtype}_{'causal' if causal else 'full'}_{'o32' if out32 else 'o16'}"
         self.main, self.ool = [], []
         self.L = self.main
+        self.abl_on = False
         self.uid = 0
 
     # ---- emission helpers ------------------------------------------------------------------------------------------------
     def i(self, s):
+        if self.abl_on and ABL:            # TIMING-ONLY ablations of the FULL body (wrong results): drop one instruction class
+            op = s.split()[0]
+            drop = {"noadd": op == "v_add_f32", "noexp": op == "v_exp_f32", "nofma": op == "v_fma_f32", "nocvt": op.startswith("v_cvt_pk"),
+                    "nomax": op.startswith("v_max"), "nodma2": op.startswith("buffer_load"), "nolds": op.startswith("ds_read") or s.startswith("s_waitcnt lgkmcnt"),
+                    "noqk": op.startswith("v_mfma") and s.split()[1].startswith("v["), "nopv": op.startswith("v_mfma") and s.split()[1].startswith("a["),
+                    "nosoftmax": op in ("v_add_f32", "v_exp_f32", "v_fma_f32", "v_max3_f32", "v_max_f32", "v_mul_f32", "v_sub_f32", "v_mov_b32", "v_cndmask_b32",
+                                        "v_cmp_gt_f32", "v_permlane32_swap_b32", "s_nop", "s_or_b64") or op.startswith("v_cvt_pk")}
+            if any(drop.get(a, False) for a in ABL.split("+")):
+                return
         self.L.append("\t" + s)
 
     def lab(self, s):
@@ -163,22 +185,81 @@ class Gen:
 
     def emit(self, lst):
         for x in lst:
-            self.i(x)
+            if x.endswith(":"):
+                self.lab(x[:-1])
+            else:
+                self.i(x)
 
     def out_of_line(self, on):
         self.L = self.ool if on else self.main
 
+    # ---- diagnostic stamps (P4_STAMP=1 at generation; never time such a build) -------------------------------------------------------
+    # a192 = previous s_memtime (low word), a[193 + k] = cycles accumulated in bucket k: 0 QK^T phase, 1 PV phase, 2 wait + barrier +
+    # stream bookkeeping, 3 item switch + prologue, 4 epilogue, 5 LAST bodies, 6 SKIP bodies, 7 FULL iterations (count), 8 items (count)
+    def stamp(self, k, count=None, fine=False):
+        if not STAMP or (fine and STAMP == 2):
+            return
+        assert RING == 8, "stamps live in the VGPRs the 4-deep rings use"
+        t2 = vr(V_E[14])
+        self.i("s_memtime s[58:59]")
+        self.i("s_waitcnt lgkmcnt(0)")
+        self.i(f"v_sub_u32 {t2}, s58, v176")
+        self.i(f"v_add_u32 v{177 + k}, v{177 + k}, {t2}")
+        self.i("v_mov_b32 v176, s58")
+        if count is not None:
+            self.i(f"v_add_u32 v{177 + count}, 1, v{177 + count}")
+
+    def stamp_init(self):
+        if not STAMP:
+            return
+        for k in range(177, 193):
+            self.i(f"v_mov_b32 v{k}, 0")
+        self.i("s_memtime s[58:59]")
+        self.i("s_waitcnt lgkmcnt(0)")
+        self.i("v_mov_b32 v176, s58")
+        self.i("v_mov_b32 v187, s58")                                # bucket 10: cycle counter at kernel start
+        self.i("s_memrealtime s[58:59]")
+        self.i("s_waitcnt lgkmcnt(0)")
+        self.i("v_mov_b32 v188, s58")                                # bucket 11: 100 MHz counter at kernel start
+
+    def stamp_dump(self):
+        """[workgroup][wave][16] dwords into the dbg buffer (kernarg), by lane 0."""
+        if not STAMP:
+            return
+        t3 = vr(V_E[15])
+        lskip = self.ul("nodbg")
+        self.i(f"s_cmp_eq_u64 {ka('dbg', 2)}, 0")
+        self.i(f"s_cbranch_scc1 {lskip}")
+        self.i("s_memtime s[58:59]")
+        self.i("s_waitcnt lgkmcnt(0)")
+        self.i("v_sub_u32 v187, s58, v187")                          # total cycles
+        self.i("s_memrealtime s[58:59]")
+        self.i("s_waitcnt lgkmcnt(0)")
+        self.i("v_sub_u32 v188, s58, v188")                          # total 10-ns ticks
+        self.i(f"s_mov_b32 {S('lsrd', 0)}, {ka('dbg')}")
+        self.i(f"s_and_b32 {S('lsrd', 1)}, {ka('dbg', hi=True)}, 0xffff")
+        self.i(f"s_mov_b32 {S('lsrd', 2)}, 0x7fffffff")
+        self.i(f"s_lshl_b32 {S('t0')}, s2, 2")
+        self.i(f"s_add_u32 {S('t0')}, {S('t0')}, {S('wave')}")
+        self.i(f"s_lshl_b32 {S('t0')}, {S('t0')}, 6")                # ((wg * 4 + wave) * 16) * 4 bytes
+        self.i(f"v_mov_b32 {t3}, 0")
+        self.i("s_mov_b64 exec, 1")
+        for k in range(16):
+            self.i(f"buffer_store_dword v{176 + k}, {t3}, {S('lsrd')}, {S('t0')} offen offset:{4 * k}")
+        self.i("s_mov_b64 exec, -1")
+        self.lab(lskip)
+
     # ---- building blocks -------------------------------------------------------------------------------------------------
     def kread(self, slot, i):                 # K fragment i = (kb, ks) of the K tile in ring slot `slot` -> ring register i % 4
         kb, ks = i // 8, i % 8
-        return f"ds_read_b128 {vr(KFR(i), 4)}, {vr(KOFF(ks))} offset:{K_BASE + slot * TILE + kb * HALF}"
+        return f"ds_read_b128 {fr(KFR(i), 4)}, {vr(KOFF(ks))} offset:{K_BASE + slot * TILE + kb * HALF}"
 
     def vread(self, slot, idx):               # V^T fragment idx = (f, db): two transposed 8-byte reads (rows +0 / +8)
         f, db = idx // 4, idx % 4
         ko = slot * TILE + (f // 2) * HALF + (f & 1) * 16 * 256
         b = VFR(idx)
-        return [f"ds_read_b64_tr_b16 {vr(b, 2)}, {vr(VOFF(db, 0))} offset:{ko}",
-                f"ds_read_b64_tr_b16 {vr(b + 2, 2)}, {vr(VOFF(db, 1))} offset:{ko}"]
+        return [f"ds_read_b64_tr_b16 {fr(b, 2)}, {vr(VOFF(db, 0))} offset:{ko}",
+                f"ds_read_b64_tr_b16 {fr(b + 2, 2)}, {vr(VOFF(db, 1))} offset:{ko}"]
 
     def dma(self, which, t):                  # piece t of this wave's four (M0 already points at the wave's 4 KiB of the slot)
         off, srd, so = (KDOFF(t), S("ksrd"), S("koff")) if which == 'K' else (VDOFF(t), S("vsrd"), S("voff"))
@@ -187,28 +268,35 @@ class Gen:
     def setm0(self, which, slot):             # M0 = this wave's 4 KiB of ring slot `slot` of the K / V ring  (clobbers SCC)
         return f"s_add_u32 m0, {S('w4k')}, {(K_BASE if which == 'k' else V_BASE) + slot * TILE}"
 
-    # softmax FINISH of strip X on buffer `buf`: the exponentials of key block 1 and all sixteen P dwords
-    def finish_fill(self, X, buf, e):
+    # softmax FINISH of strip X on buffer `buf`: the exponentials of key block 1 and all sixteen P dwords, as an in-order stream.
+    # The v_fma of element e+1 is issued ahead of the v_exp of element e and no two dependent adds are adjacent (a dependent VALU
+    # pair costs issue stalls: SQ_WAIT_INST_ANY was 15 % of the wave's cycles with fma -> exp and add -> add back to back).
+    def finish_stream(self, X, buf):
         c1 = lambda k: vr(SBUF(buf, X, 1, k))
         c0 = lambda k: vr(SBUF(buf, X, 0, k))
-        o = [f"v_fma_f32 {c1(e)}, {c1(e)}, {ka('scale_log2')}, -{vr(STV(X, 'mc'))}", f"v_exp_f32 {c1(e)}, {c1(e)}"]
-        if e == 0:
-            o.append(f"v_add_f32 {vr(STV(X, 'ps0'))}, {vr(STV(X, 'ps0'))}, {c0(15)}")
-        if e % 2 == 0:
-            o.append(f"{self.cvt} {vr(PD(X, e // 2))}, {c0(e)}, {c0(e + 1)}")
-            if e >= 4:
-                o.append(f"v_add_f32 {vr(V_PS1)}, {vr(V_PS1)}, {c1(e - 4)}")
+        mc, ps0, l = vr(STV(X, 'mc')), vr(STV(X, 'ps0')), vr(STV(X, 'l'))
+        fma = lambda e: f"v_fma_f32 {c1(e)}, {c1(e)}, {ka('scale_log2')}, -{mc}"
+        o = [fma(0)]
+        for e in range(16):
+            if e < 15:
+                o.append(fma(e + 1))
+            o.append(f"v_exp_f32 {c1(e)}, {c1(e)}")
+            if e == 0:
+                o.append(f"v_add_f32 {ps0}, {ps0}, {c0(15)}")      # left over from the start (its sums lag by one element)
+            if e % 2 == 0:
+                o.append(f"{self.cvt} {vr(PD(X, e // 2))}, {c0(e)}, {c0(e + 1)}")
+            elif e >= 3:
+                o.append(f"{self.cvt} {vr(PD(X, 8 + (e - 3) // 2))}, {c1(e - 3)}, {c1(e - 2)}")
+            if e >= 3:
                 o.append(f"v_add_f32 {vr(V_PS1)}, {vr(V_PS1)}, {c1(e - 3)}")
-        elif e >= 3:
-            o.append(f"{self.cvt} {vr(PD(X, 8 + (e - 3) // 2))}, {c1(e - 3)}, {c1(e - 2)}")
-        return o
-
-    def finish_end(self, X, buf):
-        c1 = lambda k: vr(SBUF(buf, X, 1, k))
-        o = [f"v_add_f32 {vr(V_PS1)}, {vr(V_PS1)}, {c1(k)}" for k in range(12, 16)]
+        o.append(f"v_add_f32 {vr(V_PS1)}, {vr(V_PS1)}, {c1(13)}")
         o.append(f"{self.cvt} {vr(PD(X, 15))}, {c1(14)}, {c1(15)}")
-        o.append(f"v_add_f32 {vr(STV(X, 'l'))}, {vr(STV(X, 'l'))}, {vr(STV(X, 'ps0'))}")
-        o.append(f"v_add_f32 {vr(STV(X, 'l'))}, {vr(STV(X, 'l'))}, {vr(V_PS1)}")
+        o.append(f"v_add_f32 {l}, {l}, {ps0}")
+        o.append(f"v_add_f32 {vr(V_PS1)}, {vr(V_PS1)}, {c1(14)}")
+        o.append(f"v_mov_b32 {ps0}, 0")
+        o.append(f"v_add_f32 {vr(V_PS1)}, {vr(V_PS1)}, {c1(15)}")
+        o.append("s_nop 0")
+        o.append(f"v_add_f32 {l}, {l}, {vr(V_PS1)}")
         o.append(f"v_mov_b32 {vr(V_PS1)}, 0")
         return o
 
@@ -245,26 +333,36 @@ class Gen:
                   f"v_mul_f32 {mc}, {ka('scale_log2')}, {t0}",
                   f"v_mul_f32 {l}, {l}, {al}"]
         else:
-            v = u - 5
-            lo, n = (v // 2) * 3 + (v & 1), (2 if (v & 1) else 1)
-            nprev = 0 if v == 0 else (1 if (v & 1) else 2)
-            for e in range(lo, lo + n):
-                o.append(f"v_fma_f32 {n0(e)}, {n0(e)}, {ka('scale_log2')}, -{mc}")
-            for e in range(lo, lo + n):
-                o.append(f"v_exp_f32 {n0(e)}, {n0(e)}")
-            for e in range(lo - nprev, lo):
-                o.append(f"v_add_f32 {ps0}, {ps0}, {n0(e)}")
+            raise ValueError("u >= 5: see start_stream")
+        return o
+
+    def start_stream(self, X, buf):
+        """row max, defer-max update, then the exponentials of key block 0 (fma one element ahead, sums one behind; element 15's
+        sum is added by the finish)"""
+        n0 = lambda k: vr(SBUF(buf, X, 0, k))
+        mc, ps0 = vr(STV(X, 'mc')), vr(STV(X, 'ps0'))
+        fma = lambda e: f"v_fma_f32 {n0(e)}, {n0(e)}, {ka('scale_log2')}, -{mc}"
+        o = []
+        for u in range(5):
+            o += self.start_fill(X, buf, u)
+        o.append(fma(0))
+        for e in range(16):
+            if e < 15:
+                o.append(fma(e + 1))
+            o.append(f"v_exp_f32 {n0(e)}, {n0(e)}")
+            if e >= 1:
+                o.append(f"v_add_f32 {ps0}, {ps0}, {n0(e - 1)}")
         return o
 
     def qk_mfma(self, buf, X, i):
         kb, ks = i // 8, i % 8
         acc = vr(SBUF(buf, X, kb, 0), 16)
-        return f"{self.mf} {acc}, {vr(KFR(i), 4)}, {ar(QA(X, ks), 4)}, {'0' if ks == 0 else acc}"
+        return f"{self.mf} {acc}, {fr(KFR(i), 4)}, {ar(QA(X, ks), 4)}, {'0' if ks == 0 else acc}"
 
     def pv_mfma(self, X, idx):
         f, db = idx // 4, idx % 4
         acc = ar(OA(X, db), 16)
-        return f"{self.mf} {acc}, {vr(VFR(idx), 4)}, {vr(PD(X, 4 * f), 4)}, {acc}"
+        return f"{self.mf} {acc}, {fr(VFR(idx), 4)}, {vr(PD(X, 4 * f), 4)}, {acc}"
 
     # ---- phases ----------------------------------------------------------------------------------------------------------
     def phase_qk(self, p, fillers, dma_at, lg=None, pre=(), tail_vreads=None):
@@ -272,7 +370,7 @@ class Gen:
         whose first four V^T fragments are requested in the last gaps (after the last K read), for the PV phase that follows."""
         nb, slot = 1 - p, 1 - p
         lg = lg or Lgkm()
-        for i in range(4):
+        for i in range(RING):
             self.i(self.kread(slot, i))
             lg.issue(('k', i))
         self.emit(pre)
@@ -284,14 +382,14 @@ class Gen:
                     self.i(w)
             self.i(self.qk_mfma(nb, X, i))
             if hs % 2 == 1 and i % 2 == 1:
-                for f in (i + 3, i + 4):
+                for f in (i + RING - 1, i + RING):
                     if f < 16:
                         self.i(self.kread(slot, f))
                         lg.issue(('k', f))
-            if tail_vreads is not None and hs >= 28:
-                for k, x in enumerate(self.vread(tail_vreads, hs - 28)):
+            if tail_vreads is not None and hs >= 32 - RING:
+                for k, x in enumerate(self.vread(tail_vreads, hs - (32 - RING))):
                     self.i(x)
-                    lg.issue(('v', hs - 28, k))
+                    lg.issue(('v', hs - (32 - RING), k))
             self.emit(dma_at.get(hs, []))
             self.emit(fillers[hs])
         return lg
@@ -301,7 +399,7 @@ class Gen:
         slot = p
         lg = lg or Lgkm()
         if not preissued:
-            for idx in range(4):
+            for idx in range(RING):
                 for k, x in enumerate(self.vread(slot, idx)):
                     self.i(x)
                     lg.issue(('v', idx, k))
@@ -314,7 +412,7 @@ class Gen:
             for X in strips:
                 self.i(self.pv_mfma(X, idx))
                 if X == strips[-1] and idx % 2 == 1:
-                    for f in (idx + 3, idx + 4):
+                    for f in (idx + RING - 1, idx + RING):
                         if f < 16:
                             for k, x in enumerate(self.vread(slot, f)):
                                 self.i(x)
@@ -350,9 +448,12 @@ class Gen:
         self.i(f"s_sub_u32 {S('wrem')}, {S('wrem')}, 1")
         self.i(f"s_cmp_lg_u32 {S('qrem')}, 0")
         self.i(f"s_cbranch_scc1 {lq}")
+        self.stamp(2, fine=True)
         self.i("s_waitcnt vmcnt(0)")
+        self.stamp(9, fine=True)                # bucket 9: the wait for this wave's own DMA pieces
         self.lab(lb)
         self.i("s_barrier")
+        self.stamp(12, fine=True)               # bucket 12: the barrier
         self.out_of_line(True)
         self.lab(lq)
         self.q_group()
@@ -374,32 +475,87 @@ class Gen:
     def dma_plan(self, p, gaps_v, gaps_k):
         """V(j+1) -> V slot 1-p, K(j+2) -> K slot p: {gap: [instructions]}"""
         d = {}
+        def piece(which, n):
+            if not ABL:
+                return [self.dma(which, n)]
+            # TIMING-ONLY ablations (wrong results): "nodma" = no wave issues its pieces, "dma_w0" = only wave 0 does
+            lab = self.ul("abl")
+            if ABL == "nodma":
+                return [f"s_cmp_eq_u32 {S('wave')}, 99", f"s_cbranch_scc0 {lab}", self.dma(which, n), lab + ":"]
+            return [f"s_cmp_eq_u32 {S('wave')}, 0", f"s_cbranch_scc0 {lab}", self.dma(which, n), lab + ":"]
         for n, g in enumerate(gaps_v):
             d.setdefault(g, [])
             if n == 0:
                 d[g] += [self.setm0('v', 1 - p), "s_nop 0"]          # M0 write -> LDS-DMA: one wait state
-            d[g].append(self.dma('V', n))
+            d[g] += piece('V', n)
         for n, g in enumerate(gaps_k):
             d.setdefault(g, [])
             if n == 0:
                 d[g] += [self.setm0('k', p), "s_nop 0"]
-            d[g].append(self.dma('K', n))
+            d[g] += piece('K', n)
         return d
+
+    # ---- gap packing -------------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def price(ins):
+        """vector-issue cycles of one instruction beside MFMAs (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost')"""
+        op = ins.split()[0]
+        if op.endswith(":"):
+            return 0
+        if op.startswith(("v_exp", "v_log", "v_rcp")):
+            return 8
+        if op.startswith("ds_"):
+            return 2
+        if op.startswith("buffer_load"):
+            return DMA_PRICE
+        if op == "s_nop":
+            return 4 * (int(ins.split()[1]) + 1)
+        return 4
+
+    def pack(self, stream, fixed, ngaps=32, budget=24):
+        """Slice an in-order instruction stream over the MFMA gaps: gap g takes instructions while its fixed content (LDS reads,
+        waits, DMA pieces) plus what it has taken stays within the budget of issue cycles an MFMA's shadow hides.  What does not
+        fit anywhere is returned as the tail (emitted behind the last MFMA)."""
+        st = list(stream)
+        total = sum(self.price(x) for x in st)
+        room_all = sum(max(0, budget - f) for f in fixed)
+        over = max(0, total - room_all)
+        out = []
+        for g in range(ngaps):
+            room = budget - fixed[g] + (over * (g + 1)) // ngaps - (over * g) // ngaps     # spread the unavoidable excess evenly
+            take = []
+            while st and room - self.price(st[0]) >= -2:
+                room -= self.price(st[0])
+                take.append(st.pop(0))
+            out.append(take)
+        return out, st
 
     def body_full(self, p):
         self.cm(f"FULL body, parity {p}: QK^T(j+1) || softmax finish(j);  PV(j) || softmax start(j+1)")
-        fa = []
+        self.stamp(2)
+        self.abl_on = True
+        # ---- phase A: the finish of both strips as ONE in-order stream, sliced evenly over the gaps around their fixed content
+        fin = self.finish_stream('A', p) + self.finish_stream('B', p)
+        dma = self.dma_plan(p, DMA_GAPS_V, DMA_GAPS_K)
+        fixed = []
         for hs in range(32):
-            X, e = ('A', hs) if hs < 16 else ('B', hs - 16)
-            f = self.finish_fill(X, p, e)
-            if hs == 16:
-                f = self.finish_end('A', p) + f
-            fa.append(f)
-        # the first gap's fillers run while the first K fragments are on their way
-        pre, fa[0] = fa[0], []
-        # V pieces early in the QK^T phase, K pieces late: each lands well before the barrier
-        lg = self.phase_qk(p, fa, self.dma_plan(p, [1, 5, 9, 13], [17, 21, 25, 27]), pre=pre, tail_vreads=p)
-        self.emit(self.finish_end('B', p))
+            i = hs // 2
+            f = sum(self.price(x) for x in dma.get(hs, []))
+            if hs % 2 == 1 and i % 2 == 1 and i + RING - 1 < 16:
+                f += 2 * self.price("ds_read")                   # two K fragment reads
+            if hs % 2 == 1 and i % 2 == 1 and i + 1 < 16:
+                f += 4                                           # the s_waitcnt in front of the next MFMA pair
+            if hs >= 32 - RING:
+                f += 2 * self.price("ds_read")                   # V^T fragments for the PV phase
+            fixed.append(f)
+        npre = 0
+        while sum(self.price(x) for x in fin[:npre + 1]) <= 24:
+            npre += 1
+        pre, fin = fin[:npre], fin[npre:]
+        fa, tail = self.pack(fin, fixed)
+        lg = self.phase_qk(p, fa, dma, pre=pre, tail_vreads=p)
+        self.emit(tail)
+        self.stamp(0, fine=True)
         if self.causal:                        # the diagonal tile of this wave is tile wnt-1 = j+1  <=>  wrem == 1
             lm, lr = self.ul("mask"), self.ul("masked")
             self.i(f"s_cmp_eq_u32 {S('wrem')}, 1")
@@ -410,11 +566,22 @@ class Gen:
             self.mask_diag(1 - p)
             self.i(f"s_branch {lr}")
             self.out_of_line(False)
-        fb = []
+        # ---- phase B: the start of both strips, same treatment
+        sta = self.start_stream('A', 1 - p) + self.start_stream('B', 1 - p)
+        fixed = []
         for hs in range(32):
-            X, u = ('A', hs) if hs < 16 else ('B', hs - 16)
-            fb.append(self.start_fill(X, 1 - p, u))
+            idx = hs // 2
+            f = 0
+            if hs % 2 == 1 and idx % 2 == 1 and idx + RING - 1 < 16:
+                f += 4 * self.price("ds_read")
+            if hs % 2 == 1 and idx % 2 == 1 and idx + 1 < 16:
+                f += 4
+            fixed.append(f)
+        fb, tail = self.pack(sta, fixed)
         self.phase_pv(p, fb, {}, lg=lg, preissued=True)
+        self.emit(tail)
+        self.abl_on = False
+        self.stamp(1, count=7)
         # pending O rescale (rare: defer-max)
         lr, lb = self.ul("rescale"), self.ul("rescaled")
         self.i(f"s_cmp_lg_u64 {S('grow')}, 0")
@@ -428,19 +595,20 @@ class Gen:
 
     def body_last(self, p):
         self.cm(f"LAST body, parity {p}: this wave's last tile -- finish(j), PV(j); nothing to prefetch for the wave itself")
+        self.stamp(2)
         d = self.dma_plan(p, [0, 2, 4, 6], [8, 10, 12, 14])
-        for e in range(16):
-            self.emit(self.finish_fill('A', p, e))
-        self.emit(self.finish_end('A', p))
+        self.emit(self.finish_stream('A', p))
         self.i("s_nop 1")
-        fb = [self.finish_fill('B', p, e) for e in range(16)]
+        fb, tail = self.pack(self.finish_stream('B', p), [0] * 16, ngaps=16)
         self.phase_pv(p, fb, d, strips="A")
-        self.emit(self.finish_end('B', p))
+        self.emit(tail)
         self.i("s_nop 1")
         self.phase_pv(p, [[] for _ in range(16)], {}, strips="B")
+        self.stamp(5)
 
     def body_skip(self, p):
         self.cm(f"SKIP body, parity {p}: this wave is past its last tile of the item -- keep the rings fed")
+        self.stamp(2)
         self.i(self.setm0('v', 1 - p))
         self.i("s_nop 0")
         for t in range(4):
@@ -449,6 +617,7 @@ class Gen:
         self.i("s_nop 0")
         for t in range(4):
             self.i(self.dma('K', t))
+        self.stamp(6)
 
     def mask_diag(self, buf):
         """Causal mask of the wave's diagonal tile (key base = the wave's first row): key 32 kb + kidx(e) + 4h is visible to row
@@ -642,8 +811,7 @@ class Gen:
         self.i("s_nop 7")
         self.i("s_nop 7")
         for X in "AB":
-            for u in range(16):
-                self.emit(self.start_fill(X, 0, u))
+            self.emit(self.start_stream(X, 0))
         for X in "AB":
             self.i(f"v_mov_b32 {vr(STV(X, 'al'))}, 1.0")
         self.i(f"s_mov_b64 {S('grow')}, 0")
@@ -756,6 +924,7 @@ class Gen:
         self.i(f"v_readfirstlane_b32 {W}, {T0}")
         self.i("s_waitcnt lgkmcnt(0)")
         # slot / xcd of this workgroup: xcd_mode ? (xcd = wg & 7, slot = wg >> 3) : (xcd = 0, slot = wg)
+        self.stamp_init()
         self.i(f"s_and_b32 {S('xcd')}, s2, 7")
         self.i(f"s_lshr_b32 {S('slot')}, s2, 3")
         self.i(f"s_cmp_eq_u32 {ka('xcd_mode')}, 0")
@@ -902,6 +1071,7 @@ class Gen:
         self.item_prologue()
         self.i("s_waitcnt vmcnt(0)")
         self.i("s_barrier")                    # V0 / K1 published; every wave is done with K slot 0
+        self.stamp(3, count=8)
         # ---- tile loop, unrolled by the two S buffers ----------------------------------------------------------------------------------
         lloop = f".L{n}_loop"
         self.lab(lloop)
@@ -926,9 +1096,12 @@ class Gen:
         self.i(f"s_sub_u32 {S('irem')}, {S('irem')}, 2")
         self.i(f"s_cmp_gt_i32 {S('irem')}, 0")
         self.i(f"s_cbranch_scc1 {lloop}")
+        self.stamp(2)
         self.item_epilogue()
+        self.stamp(4)
         self.i(f"s_cmp_lg_u32 {S('n_valid')}, 0")
         self.i(f"s_cbranch_scc1 {litem}")
+        self.stamp_dump()
         self.lab(lend)
         self.i("s_endpgm")
         self.main += self.ool

@@ -148,7 +148,8 @@ int p4_launch(const pfa_fa3_args* a, void* stream, int* hip_err) {
     p.hx = p.xcd_mode ? (uint32_t)(BH / 8) : (uint32_t)BH;
     p.SL = p.xcd_mode ? (uint32_t)(grid / 8) : (uint32_t)grid;
     p.nt_full = (uint32_t)(a->Sk / 64);
-    p.dbg = nullptr;
+    // diagnostic build only (P4_STAMP=1 make): per-wave cycle buckets go to the caller's workspace; the production kernel never reads it
+    p.dbg = (a->workspace && a->workspace_bytes >= (size_t)grid * 4 * 16 * 4) ? (unsigned long long*)a->workspace : nullptr;
 
     size_t sz = sizeof(p);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
