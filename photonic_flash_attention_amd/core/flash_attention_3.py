@@ -146,16 +146,14 @@ class FlashAttention3(nn.Module):
         key_mask = attention_mask if (attention_mask is not None and attention_mask.dim() == 2) else None
         mask = attention_mask if (attention_mask is not None and attention_mask.dim() != 2) else None
         if needs_grad:
-            # differentiable path: HIP forward (with LSE) + HIP backward (pfa_fa3_bwd), masks included.  The returned
-            # weights would not be differentiable, so they are refused rather than silently detached.
-            if need_weights:
-                raise NotImplementedError(
-                    "need_weights under autograd is not supported on the HIP path (the weights would carry no "
-                    "gradient); call with torch.no_grad() to get them")
+            # differentiable path: HIP forward (with LSE) + HIP backward (pfa_fa3_bwd), masks included.  need_weights (the
+            # default of the nn.MultiheadAttention-shaped facade) gets the softmax matrix from the second pass on the saved
+            # LSE, DETACHED: the gradient flows through the output only.
             cd = self.compute_dtype if q.dtype == torch.float32 else q.dtype
-            out = ops.fa3_attention(q.to(cd), k.to(cd), v.to(cd), causal=is_causal, key_mask=key_mask, mask=mask,
-                                    softmax_scale=self.scaling, out_dtype=q.dtype)
-            return out, None
+            res = ops.fa3_attention(q.to(cd), k.to(cd), v.to(cd), causal=is_causal, key_mask=key_mask, mask=mask,
+                                    softmax_scale=self.scaling, out_dtype=q.dtype, return_weights=need_weights,
+                                    weights_dtype=torch.float32 if q.dtype == torch.float32 else None)
+            return (res[0], res[1]) if need_weights else (res, None)
 
         kw = dict(causal=is_causal, key_mask=key_mask, mask=mask, softmax_scale=self.scaling,
                   return_weights=need_weights)

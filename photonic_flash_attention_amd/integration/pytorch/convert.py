@@ -49,12 +49,23 @@ class TorchMHAReplacement(PhotonicMultiHeadAttention):
 
     @staticmethod
     def _to_keep_mask(mask: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
-        """PyTorch mask (bool: True = drop; float: additive, -inf = drop) -> keep-mask (non-zero = attend)."""
+        """PyTorch mask (bool: True = drop; float: additive) -> keep-mask (non-zero = attend).
+
+        ``nn.MultiheadAttention`` ADDS a float mask to the scores.  The kernel takes binary masks only, so a float mask is
+        accepted when it is binary in effect -- every entry 0 (attend) or at most -1e4 / finfo.min / -inf (drop), the same
+        threshold as ``hf._keep_mask`` -- and refused otherwise: finite biases (ALiBi, relative position terms) would be
+        dropped silently."""
         if mask is None:
             return None
         if mask.dtype == torch.bool:
             return ~mask
-        return torch.isfinite(mask) & (mask > -1e30)
+        keep = mask > -1.0
+        soft = (keep & (mask != 0)) | (~keep & (mask > -1e4))
+        if bool(soft.any()):
+            raise ValueError("float attn_mask / key_padding_mask with finite biases is not supported by the converted layer: "
+                             "entries must be 0 (attend) or <= -1e4 / -inf (masked); additive biases such as ALiBi or "
+                             "relative-position terms cannot be expressed as a binary mask")
+        return keep
 
     def forward(self, query, key, value, key_padding_mask=None, need_weights=True, attn_mask=None,
                 average_attn_weights=True, is_causal=False):

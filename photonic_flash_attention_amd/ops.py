@@ -14,7 +14,7 @@ No fallback lives here: unsupported arguments raise ``ValueError`` (pre-launch
 from __future__ import annotations
 
 import ctypes as C
-import os
+import threading
 from typing import Optional, Tuple
 
 import torch
@@ -57,6 +57,7 @@ def is_available(device: Optional[torch.device] = None) -> bool:
 
 
 _SEQLENS_CACHE: "dict[tuple, torch.Tensor]" = {}
+_SEQLENS_LOCK = threading.Lock()      # the wrappers above this module are entered from several threads (hybrid_router's pool)
 
 
 def _seqlens_tensor(seqlens_k, device) -> torch.Tensor:
@@ -65,11 +66,12 @@ def _seqlens_tensor(seqlens_k, device) -> torch.Tensor:
     if isinstance(seqlens_k, torch.Tensor):
         return seqlens_k.to(device=device, dtype=torch.int32).contiguous()
     key = (tuple(int(x) for x in seqlens_k), str(device))
-    t = _SEQLENS_CACHE.get(key)
-    if t is None:
-        if len(_SEQLENS_CACHE) >= 64:
-            _SEQLENS_CACHE.clear()
-        t = _SEQLENS_CACHE[key] = torch.tensor(key[0], dtype=torch.int32, device=device)
+    with _SEQLENS_LOCK:
+        t = _SEQLENS_CACHE.get(key)
+        if t is None:
+            if len(_SEQLENS_CACHE) >= 64:
+                _SEQLENS_CACHE.clear()
+            t = _SEQLENS_CACHE[key] = torch.tensor(key[0], dtype=torch.int32, device=device)
     return t
 
 
@@ -210,8 +212,8 @@ def fa3_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: bo
             out.copy_(o)
             o = out
         return (o,) + tuple(res[1:])
-    if _variant is None:   # development only: experimental kernel variant (include/pfa_hip.h PFA_FLAG_VARIANT_MASK)
-        _variant = int(os.environ.get("PFA_VARIANT", "0"))
+    if _variant is None:   # tools / tests only: kernel selector (include/pfa_hip.h PFA_FLAG_VARIANT_MASK); never read from the environment
+        _variant = 0
     odt = q.dtype if out_dtype is None else out_dtype
     if split_p is None:
         split_p = odt == torch.float32
@@ -320,24 +322,33 @@ class _FA3Function(torch.autograd.Function):
     backward's delta = rowsum(dO o O)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, causal, seqlens_k, softmax_scale, key_mask, mask, out_dtype):
-        out, lse = fa3_forward(q, k, v, causal=causal, seqlens_k=seqlens_k, key_mask=key_mask, mask=mask,
-                               softmax_scale=softmax_scale, return_lse=True, out_dtype=out_dtype)
+    def forward(ctx, q, k, v, causal, seqlens_k, softmax_scale, key_mask, mask, out_dtype, want_weights, weights_dtype):
+        res = fa3_forward(q, k, v, causal=causal, seqlens_k=seqlens_k, key_mask=key_mask, mask=mask,
+                          softmax_scale=softmax_scale, return_lse=True, out_dtype=out_dtype,
+                          return_weights=want_weights, weights_dtype=weights_dtype)
+        out, lse = res[0], res[1]
         o16 = out if out.dtype == q.dtype else out.to(q.dtype)
         ctx.save_for_backward(q, k, v, o16, lse)
         ctx.causal, ctx.seqlens_k, ctx.softmax_scale = causal, seqlens_k, softmax_scale
         ctx.key_mask, ctx.mask = key_mask, mask          # masks carry no gradient
+        if want_weights:
+            # the softmax matrix from the second pass on the saved LSE: returned for inspection (nn.MultiheadAttention's
+            # default need_weights=True), detached -- the gradient flows through the output only
+            ctx.mark_non_differentiable(res[2])
+            return out, res[2]
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, *_dweights):
         q, k, v, out, lse = ctx.saved_tensors
         dq, dk, dv = fa3_backward(q, k, v, out, dout.to(q.dtype), lse, causal=ctx.causal, seqlens_k=ctx.seqlens_k,
                                   key_mask=ctx.key_mask, mask=ctx.mask, softmax_scale=ctx.softmax_scale)
-        return dq, dk, dv, None, None, None, None, None, None
+        return dq, dk, dv, None, None, None, None, None, None, None, None
 
 
 def fa3_attention(q, k, v, *, causal: bool = False, seqlens_k=None, key_mask=None, mask=None,
-                  softmax_scale: Optional[float] = None, out_dtype: Optional[torch.dtype] = None):
-    """Autograd-aware attention on ``[B,H,S,D]`` bf16/fp16 operands: forward + backward on the HIP kernels."""
-    return _FA3Function.apply(q, k, v, causal, seqlens_k, softmax_scale, key_mask, mask, out_dtype)
+                  softmax_scale: Optional[float] = None, out_dtype: Optional[torch.dtype] = None,
+                  return_weights: bool = False, weights_dtype: Optional[torch.dtype] = None):
+    """Autograd-aware attention on ``[B,H,S,D]`` bf16/fp16 operands: forward + backward on the HIP kernels.
+    ``return_weights=True`` -> ``(out, weights)``; the weights are detached (no gradient flows through them)."""
+    return _FA3Function.apply(q, k, v, causal, seqlens_k, softmax_scale, key_mask, mask, out_dtype, bool(return_weights), weights_dtype)

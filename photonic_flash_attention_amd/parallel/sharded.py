@@ -28,6 +28,23 @@ import torch
 import torch.distributed as dist
 
 GATHER_ALGO = "all_gather_into_tensor"
+GATHER_ALGOS = ("all_gather_into_tensor", "direct")
+
+
+def _direct_gather(buf: torch.Tensor, src: torch.Tensor, group=None) -> None:
+    """The combine as W-1 concurrent point-to-point exchanges instead of a collective: rank r sends its shard to every peer and
+    receives every peer's shard straight into its slot of ``buf`` ([W, ...]), all posted in ONE ``batch_isend_irecv`` group.  xGMI
+    is a full mesh of point-to-point links (7 per GPU), so the W-1 transfers of a rank run on W-1 different links at the same
+    time -- a ring all-gather pushes the same bytes over one link in W-1 serial steps."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    buf[rank].copy_(src)
+    ops = []
+    for d in range(1, world):                      # distance d: send to rank+d, receive from rank-d (every pair meets once per d)
+        to, frm = (rank + d) % world, (rank - d) % world
+        ops.append(dist.P2POp(dist.isend, src, to if group is None else dist.get_global_rank(group, to), group))
+        ops.append(dist.P2POp(dist.irecv, buf[frm], frm if group is None else dist.get_global_rank(group, frm), group))
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
 
 
 def shard_plan(B: int, H: int, world: int) -> Tuple[str, int]:
@@ -50,8 +67,11 @@ def local_slice(t: torch.Tensor, plan: Tuple[str, int], rank: int) -> torch.Tens
 
 
 def gather_outputs(out_local: torch.Tensor, plan: Tuple[str, int] = ("batch", 0), group=None,
-                   timed: bool = False):
-    """All-gather the per-rank ``[B_l,S,H_l,D]`` outputs into the full ``[B,S,H,D]`` tensor."""
+                   timed: bool = False, algo: str = GATHER_ALGO):
+    """Gather the per-rank ``[B_l,S,H_l,D]`` outputs into the full ``[B,S,H,D]`` tensor on every rank: ``algo`` =
+    "all_gather_into_tensor" (RCCL's collective) or "direct" (W-1 concurrent peer exchanges, one per xGMI link)."""
+    if algo not in GATHER_ALGOS:
+        raise ValueError(f"gather algo must be one of {GATHER_ALGOS}")
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return (out_local, 0.0) if timed else out_local
@@ -62,7 +82,10 @@ def gather_outputs(out_local: torch.Tensor, plan: Tuple[str, int] = ("batch", 0)
     if src.is_cuda:
         torch.cuda.synchronize(src.device)
         t0 = time.perf_counter()
-    dist.all_gather_into_tensor(flat, src, group=group)
+    if algo == "direct":
+        _direct_gather(buf, src, group)
+    else:
+        dist.all_gather_into_tensor(flat, src, group=group)
     if src.is_cuda:
         torch.cuda.synchronize(src.device)
     ms = (time.perf_counter() - t0) * 1e3
@@ -92,20 +115,48 @@ def sharded_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, caus
         def compute(a, b, c, **kk):
             return ops.fa3_forward_bshd(a, b, c, **kk)[0]
     ql, kl, vl = (local_slice(t, plan, rank) for t in (q, k, v))
+    n = plan[1]
     if "seqlens_k" in kw and kw["seqlens_k"] is not None and plan[0] == "batch":
-        n = plan[1]
         kw = dict(kw, seqlens_k=list(kw["seqlens_k"])[rank * n:(rank + 1) * n])
+    # masks follow their shard: a [B,Sk] key mask along B; a reference-style mask along its batch / head dimension unless that
+    # dimension broadcasts (size 1)
+    if kw.get("key_mask") is not None and plan[0] == "batch":
+        kw = dict(kw, key_mask=kw["key_mask"][rank * n:(rank + 1) * n])
+    if kw.get("mask") is not None:
+        m = kw["mask"]
+        if m.dim() == 2 and plan[0] == "batch" and m.shape[0] == B:          # [B,Sk]
+            m = m[rank * n:(rank + 1) * n]
+        elif m.dim() == 4:
+            if plan[0] == "batch" and m.shape[0] == B and B > 1:
+                m = m[rank * n:(rank + 1) * n]
+            elif plan[0] == "head" and m.shape[1] == H and H > 1:
+                m = m[:, rank * n:(rank + 1) * n]
+        kw = dict(kw, mask=m)
     out_local = compute(ql, kl, vl, causal=causal, **kw)
     if not gather or world == 1:
         return out_local
     return gather_outputs(out_local, plan, group)
 
 
-def overlapped_forward_gather(step: Callable[[], None], out_local: torch.Tensor, steps: int, group=None) -> float:
+def overlapped_forward_gather(step: Callable[[], None], out_local: torch.Tensor, steps: int, group=None,
+                              algo: str = GATHER_ALGO) -> float:
     """Secondary measurement: one gather per forward, issued on a side stream so that the gather of
-    step i overlaps the kernel of step i+1 (double-buffered gather target).  Returns ms per step."""
+    step i overlaps the kernel of step i+1 (double-buffered gather target).  Returns ms per step.  With host tensors (a "gloo"
+    rehearsal of the control flow) the forward and the gather simply alternate."""
     world = dist.get_world_size(group)
     dev = out_local.device
+    if not out_local.is_cuda:
+        flat = torch.empty((world * out_local.shape[0],) + tuple(out_local.shape[1:]), dtype=out_local.dtype)
+        dist.barrier(group)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+            if algo == "direct":
+                _direct_gather(flat.view((world,) + tuple(out_local.shape)), out_local.contiguous(), group)
+            else:
+                dist.all_gather_into_tensor(flat, out_local.contiguous(), group=group)
+        dist.barrier(group)
+        return (time.perf_counter() - t0) * 1e3 / steps
     comm = torch.cuda.Stream(device=dev)
     bufs = [torch.empty((world * out_local.shape[0],) + tuple(out_local.shape[1:]), dtype=out_local.dtype, device=dev)
             for _ in range(2)]
@@ -125,7 +176,10 @@ def overlapped_forward_gather(step: Callable[[], None], out_local: torch.Tensor,
         ready.record(main)
         with torch.cuda.stream(comm):
             comm.wait_event(ready)
-            dist.all_gather_into_tensor(bufs[s], stage[s], group=group)
+            if algo == "direct":
+                _direct_gather(bufs[s].view((world,) + tuple(out_local.shape)), stage[s], group)
+            else:
+                dist.all_gather_into_tensor(bufs[s], stage[s], group=group)
             done[s] = torch.cuda.Event()
             done[s].record(comm)
     torch.cuda.synchronize(dev)

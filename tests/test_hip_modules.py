@@ -180,8 +180,8 @@ def test_grad_mode_and_dropout_rules():
     m.eval()
     assert m(x)[0].requires_grad                        # eval + autograd: differentiable through pfa_fa3_bwd
     assert m(x, attention_mask=torch.ones(1, 16, device=DEV))[0].requires_grad    # ... masks included
-    with pytest.raises(NotImplementedError):           # ... but weights would carry no gradient: refused
-        m(x, need_weights=True)
+    out, w = m(x, need_weights=True)                   # ... and the weights come back detached (second pass on the saved LSE)
+    assert out.requires_grad and w is not None and not w.requires_grad and w.shape == (1, 2, 16, 16)
     with torch.no_grad():
         assert m(x)[0].shape == x.shape                 # dropout is a no-op in eval (:174-175)
 
@@ -309,3 +309,98 @@ def test_weights_pass_writes_every_element(case):
         got = w.float().cpu()
         assert float((got - ref).abs().max()) <= (2e-3 if wdt == torch.float32 else 6e-3), (case, wdt)
         assert float(got[~keep].abs().max()) == 0.0
+
+
+def test_cli_benchmark_schema(tmp_path):
+    """Counterpart of the reference's `photonic-benchmark` (cli.py:20-145): same flags, same result keys (cli.py:91-141)."""
+    import json
+    from photonic_flash_attention_amd import cli
+    out = tmp_path / "bench.json"
+    args = cli._parser().parse_args(["--seq-lengths", "128", "640", "--batch-sizes", "2", "--embed-dim", "256",
+                                     "--num-heads", "4", "--num-iterations", "3", "--output", str(out)])
+    res = cli.benchmark(args)
+    ref_keys = {"batch_size", "seq_length", "embed_dim", "num_heads", "avg_latency_ms", "std_latency_ms",
+                "min_latency_ms", "max_latency_ms", "tokens_per_sec", "last_device_used", "gpu_calls",
+                "photonic_calls", "photonic_usage_ratio"}
+    assert len(res) == 2 and all(ref_keys <= set(r) for r in res)
+    assert all(r["last_device_used"] == "gpu" and r["attn_tflops"] > 0 for r in res)
+    data = json.loads(out.read_text())
+    assert set(data) == {"benchmark_info", "results"} and {"version", "timestamp", "device_info", "config"} <= set(data["benchmark_info"])
+
+
+def test_convert_to_photonic_transformer_layer_on_gpu():
+    """Converted nn.TransformerEncoderLayer (bf16, our kernel; weight rule of the reference's convert.py:441-452) vs the
+    ORIGINAL torch layer in fp32 on the CPU."""
+    import torch.nn as nn
+    from photonic_flash_attention_amd import convert_to_photonic
+    torch.manual_seed(1)
+    layer = nn.TransformerEncoderLayer(d_model=512, nhead=4, dim_feedforward=1024, dropout=0.0, batch_first=True).eval()
+    x = torch.from_numpy(synth.normal_f32((2, 300, 512), 21))
+    pad = torch.zeros(2, 300, dtype=torch.bool)
+    pad[1, 250:] = True
+    causal = nn.Transformer.generate_square_subsequent_mask(300)
+    conv, rep = convert_to_photonic(layer, dtype=torch.bfloat16)
+    assert rep.converted_layers == ["self_attn"]
+    conv = conv.to(DEV).to(torch.bfloat16)
+    with torch.no_grad():
+        for kw in (dict(), dict(src_key_padding_mask=pad), dict(src_mask=causal, is_causal=True), dict(src_mask=causal)):
+            want = layer(x, **kw)
+            kw_dev = {k_: (v_.to(DEV) if torch.is_tensor(v_) else v_) for k_, v_ in kw.items()}
+            got = conv(x.to(DEV, torch.bfloat16), **kw_dev).float().cpu()
+            keep = ~pad if "src_key_padding_mask" in kw else torch.ones(2, 300, dtype=torch.bool)
+            err = float((got - want)[keep].abs().max())
+            assert err <= 0.12, (list(kw), err)            # bf16 end-to-end layer (LayerNorm + FFN in bf16)
+            assert float((got - want)[keep].abs().mean()) <= 0.012
+        alibi = (-0.25 * torch.arange(300.0))[None, :].expand(300, 300).contiguous().to(DEV)
+        with pytest.raises(ValueError, match="finite biases"):
+            conv(x.to(DEV, torch.bfloat16), src_mask=alibi)
+
+
+@pytest.mark.parametrize("batch_first", [False, True])
+def test_mha_facade_numbers_against_the_oracle(batch_first):
+    """PhotonicMultiHeadAttention (reference modules.py:235-336): both layouts, key_padding_mask, attn_mask + key_padding_mask
+    merged by `+` (:310-315: a score is masked only where BOTH masks are 0), head-averaged weights (:324-325) -- OUTPUT and
+    WEIGHTS compared with the oracle's module restatement; the default call (need_weights=True) also with autograd on."""
+    from photonic_flash_attention_amd import PhotonicMultiHeadAttention
+    orc = _oracle()
+    E, H, L, N = 256, 4, 136, 2
+    mha = PhotonicMultiHeadAttention(E, H, batch_first=batch_first, dtype=torch.bfloat16).to(DEV).eval()
+    mha.gpu_attention.load_state_dict({k_: v_.to(DEV) for k_, v_ in _state(E, 40).items()})
+    sd = {k_: v_.float().cpu() for k_, v_ in mha.gpu_attention.state_dict().items()}
+    xb = torch.from_numpy(synth.normal_f32((N, L, E), 3)).to(torch.bfloat16)                 # (N, L, E)
+    x = (xb if batch_first else xb.transpose(0, 1).contiguous()).to(DEV)
+    kpm = torch.ones(N, L)
+    kpm[0, 100:] = 0
+    kpm[1, 64:] = 0
+    am = torch.tril(torch.ones(L, L))                                                        # 0 = masked
+    cases = {
+        "none": (None, None, None),
+        "kpm": (kpm, None, kpm[:, None, None, :]),
+        "am+kpm": (kpm, am, ((am[None] + kpm[:, None, :]) != 0).float()[:, None]),           # the reference's `+` merge
+    }
+    for name, (kp, a_m, ref_mask) in cases.items():
+        ref = orc.module_forward(sd, H, xb.float(), mask=ref_mask)
+        kw = dict(key_padding_mask=None if kp is None else kp.to(DEV), attn_mask=None if a_m is None else a_m.to(DEV))
+        with torch.no_grad():
+            out, w = mha(x, x, x, **kw)                                                     # need_weights defaults to True
+        outb = out if batch_first else out.transpose(0, 1)
+        assert outb.shape == (N, L, E) and w.shape == (N, L, L)
+        err = float((outb.float().cpu() - ref).abs().max())
+        assert err <= 3e-2, (name, err)                                                     # bf16 projections + bf16 core
+        # weights: head average of the true softmax of the oracle's scores
+        q, k_, _v = torch.nn.functional.linear(xb.float(), sd["qkv_proj.weight"], sd["qkv_proj.bias"]).chunk(3, dim=-1)
+        sc = torch.einsum("nlhd,nshd->nhls", q.view(N, L, H, -1), k_.view(N, L, H, -1)) * (E // H) ** -0.5
+        if ref_mask is not None:
+            sc = sc.masked_fill(ref_mask.expand(N, H, L, L) == 0 if ref_mask.dim() == 4 else ref_mask == 0, float("-inf"))
+        wref = torch.softmax(sc, dim=-1).mean(dim=1)
+        assert float((w.float().cpu() - wref).abs().max()) <= 2e-2, name
+        assert float((w.float().sum(-1) - 1).abs().max()) <= 8e-3
+    # the plain default-argument call under autograd (training or eval): output differentiable, weights returned detached
+    xg = x.clone().requires_grad_(True)
+    out, w = mha(xg, xg, xg)
+    assert w is not None and not w.requires_grad and out.requires_grad
+    out.float().square().mean().backward()
+    assert xg.grad is not None and bool(torch.isfinite(xg.grad.float()).all()) and float(xg.grad.float().abs().max()) > 0
+    ref = orc.module_forward(sd, H, xb.float())
+    outb = out if batch_first else out.transpose(0, 1)
+    assert float((outb.detach().float().cpu() - ref).abs().max()) <= 3e-2

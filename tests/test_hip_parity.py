@@ -3,8 +3,13 @@
 
 Tolerances (DESIGN.md "numerics"):
   * PARITY variant (fp32 store, P as bf16 hi+lo):   max-abs <= 1e-3   (north_star bar)
-  * FAST variant  (bf16/fp16 store, P single bf16): |err| <= 2^-8*|ref| + 2^-7   (bf16 rounding of
-    P and of the output; the bound is loose on purpose, the measured numbers are printed)
+  * FAST variant  (16-bit store, P as ONE 16-bit operand): the error is two roundings and nothing else, and the bound says so
+    per element:   |err| <= eps*|ref|  +  C_P * eps * max|v| / sqrt(n_row)  (+ 2e-6)
+    eps = 2^-9 (bf16) / 2^-11 (fp16) = half an ulp; first term = the rounding of the stored output (absent with an fp32 store);
+    second term = the rounding of P before the PV product: n_row independent roundings of relative size eps, weights summing
+    to 1, so the sum shrinks as 1/sqrt(visible keys) -- C_P = 2 covers the 4.5-sigma tail over ~1e7 elements and the
+    concentration of softmax weights on N(0,1) scores (effective key count ~ n / e).  On a causal problem the first rows see
+    1..10 keys and sit at ~5e-3; from ~300 visible keys on the whole error is below 1e-3.
 """
 
 from __future__ import annotations
@@ -33,8 +38,30 @@ def _run(q, k, v, **kw):
     return o.float().cpu(), (None if lse is None else lse.cpu())
 
 
-def _fast_ok(out, ref):
-    return bool(((out - ref).abs() <= ref.abs() * 2 ** -8 + 2 ** -7).all())
+C_P = 2.0
+
+
+def _row_keys(Sq, Sk, causal, lens=None, B=1):
+    """visible keys of every query row, [B, Sq, 1, 1] (rows with none: 1, their output is exactly zero on both sides)"""
+    n = torch.full((B, Sq), float(Sk))
+    if lens is not None:
+        n = torch.minimum(n, torch.tensor([float(x) for x in lens])[:, None])
+    if causal:
+        n = torch.minimum(n, torch.arange(1, Sq + 1, dtype=torch.float32)[None, :])
+    return n.clamp(min=1.0)[:, :, None, None]
+
+
+def _fast_bound(ref, nkeys, vmax, dtype="bf16", store16=True):
+    eps = 2.0 ** (-9 if dtype == "bf16" else -11)
+    return (ref.abs() * eps * 1.01 if store16 else 0.0) + C_P * eps * vmax / nkeys.sqrt() + 2e-6
+
+
+def _fast_ok(out, ref, nkeys, vmax, dtype="bf16", store16=True, tag=""):
+    err, bound = (out - ref).abs(), _fast_bound(ref, nkeys, vmax, dtype, store16)
+    worst = float((err / bound).max())
+    if tag:
+        print(f"{tag}: max-abs {float(err.max()):.3e}, worst error/bound {worst:.2f}")
+    return worst <= 1.0
 
 
 def test_library_loaded_and_device_supported(hip):
@@ -56,8 +83,8 @@ def test_golden_full(name):
     print(f"{name}: parity variant max-abs {err:.3e}")
     assert err <= PARITY_TOL
     out16, _ = _run(q, k, v, causal=meta["causal"], seqlens_k=lens)
-    print(f"{name}: fast variant max-abs {float((out16 - ref).abs().max()):.3e}")
-    assert _fast_ok(out16, ref)
+    nk = _row_keys(meta["Sq"], meta["Sk"], meta["causal"], lens, meta["B"])
+    assert _fast_ok(out16, ref, nk, float(v.float().abs().max()), meta["dtype"], tag=f"{name}: fast variant")
 
 
 @pytest.mark.parametrize("name", golden_names("sampled"))
@@ -73,7 +100,8 @@ def test_golden_sampled_baseline_shapes(name):
         err = float((out[b, rows, h] - ref).abs().max())
         print(f"{name} head {(b, h)}: parity max-abs {err:.3e}; fast {float((out16[b, rows, h] - ref).abs().max()):.3e}")
         assert err <= PARITY_TOL
-        assert _fast_ok(out16[b, rows, h], ref)
+        nk = _row_keys(meta["Sq"], meta["Sk"], meta["causal"])[0, rows, 0]          # [rows, 1]
+        assert _fast_ok(out16[b, rows, h], ref, nk, float(v.float().abs().max()), meta["dtype"])
         hs = float(out[b, :, h].double().sum())
         assert abs(hs - arr["head_sum"][i]) <= 2e-5 * arr["head_abs_sum"][i] + 1e-2
 
@@ -106,7 +134,33 @@ def test_vs_oracle(case, dtype):
     ref_lse = orc.lse_bshd(q, k, causal=causal, seqlens_k=lens)
     assert float((lse - ref_lse).abs().max()) <= 2e-3
     out16, _ = _run(q, k, v, causal=causal, seqlens_k=lens)
-    assert _fast_ok(out16, ref)
+    assert _fast_ok(out16, ref, _row_keys(Sq, Sk, causal, lens, B), float(v.float().abs().max()), dtype)
+
+
+@pytest.mark.parametrize("name", ["g6_c3", "g6_c5"])
+def test_single_p_error_is_p_rounding_and_store_rounding_only(name):
+    """The benched schedule's 7e-3 on a causal problem, taken apart against the REFERENCE's own outputs (sampled rows of the
+    C3 / C5 goldens): with an fp32 store and ONE 16-bit P operand the only rounding left is P's, and it obeys the per-row bound
+    C_P * 2^-9 * max|v| / sqrt(visible keys) on every row -- below 1e-3 from a few hundred visible keys on; the 16-bit store adds
+    its half ulp, 2^-9 |o|, and nothing else."""
+    matches = [n for n in golden_names("sampled") if n.startswith(name)]
+    assert matches, "sampled golden missing"
+    meta, arr = load_golden(matches[0])
+    q, k, v = golden_inputs(meta)
+    rows = torch.from_numpy(arr["rows"])
+    vmax = float(v.float().abs().max())
+    o32, _ = _run(q, k, v, causal=meta["causal"], out_dtype=torch.float32, split_p=False)       # single P, fp32 store
+    o16, _ = _run(q, k, v, causal=meta["causal"])                                                # the benched kernel
+    nk = _row_keys(meta["Sq"], meta["Sk"], meta["causal"])[0, rows, 0]
+    n_1e3 = (C_P * 2.0 ** -9 * vmax / 1e-3) ** 2                    # visible keys from which the P-rounding bound itself is < 1e-3
+    for i, (b, h) in enumerate(meta["heads"]):
+        ref = torch.from_numpy(arr["out"][i])
+        assert _fast_ok(o32[b, rows, h], ref, nk, vmax, store16=False, tag=f"{matches[0]} head {(b, h)} single P, fp32 store")
+        assert _fast_ok(o16[b, rows, h], ref, nk, vmax, store16=True, tag=f"{matches[0]} head {(b, h)} benched kernel")
+        late = nk[:, 0] >= n_1e3
+        assert bool(late.any()) and float((o32[b, rows, h] - ref)[late].abs().max()) <= 1e-3
+        # the store rounding alone: the 16-bit result is the fp32-store result rounded once
+        assert float((o16[b, rows, h] - o32[b, rows, h]).abs().max()) <= float(ref.abs().max()) * 2.0 ** -8 + 1e-6
 
 
 def test_strided_views_of_fused_qkv():
@@ -217,17 +271,22 @@ def test_reentrant_from_threads_on_side_streams():
 
 
 def test_runs_to_run_determinism_and_variant_equivalence():
-    """Bitwise reproducibility of the production kernel, and the development schedules (register staging,
-    LDS-DMA, staggered wave halves, 3-slot ring ...) compute bit-identical results."""
+    """Bitwise reproducibility of every production kernel; the two HIP kernels (8 waves x 32 rows, 4 waves x 64 rows) share every
+    formula and are bit-identical with 16-bit stores; the persistent assembly kernel sums its rows in another order and agrees
+    to one rounding of the output.  Development variants do not exist in this library (PFA_ERR_FLAGS)."""
     from photonic_flash_attention_amd import ops, synth
     dev = _dev()
     q, k, v = (t.to(dev) for t in synth.qkv(1, 4, 1536, 1536, 128, 505, "bf16"))
-    base, _ = ops.fa3_forward_bshd(q, k, v, causal=True)
-    again, _ = ops.fa3_forward_bshd(q, k, v, causal=True)
-    assert torch.equal(base, again)
-    for var in (2, 3, 4, 6, 9, 10, 11, 12, 18, 35):
-        o, _ = ops.fa3_forward_bshd(q, k, v, causal=True, _variant=var)
-        assert torch.equal(o, base), f"variant {var}"
+    outs = {}
+    for var in (0, 43, 44, 45):
+        a, _ = ops.fa3_forward_bshd(q, k, v, causal=True, _variant=var)
+        b, _ = ops.fa3_forward_bshd(q, k, v, causal=True, _variant=var)
+        assert torch.equal(a, b), f"selector {var} is not reproducible"
+        outs[var] = a.float()
+    assert torch.equal(outs[43], outs[44])
+    assert float((outs[45] - outs[44]).abs().max()) <= float(outs[44].abs().max()) * 2.0 ** -8
+    with pytest.raises(ValueError):
+        ops.fa3_forward_bshd(q, k, v, causal=True, _variant=9)
 
 
 # ---- development variant 43: 4 waves x 64 rows, one wave per SIMD (csrc/fa3_fwd_w4_kernel.h) ----------------------------
@@ -293,6 +352,90 @@ def test_w4_variant_random_shapes_against_the_8_wave_kernel():
         dead = torch.isinf(l0)
         assert torch.equal(dead, torch.isinf(l1)), tag
         assert float((l0 - l1)[~dead].abs().max() if bool((~dead).any()) else 0.0) <= 3e-5, tag
+
+
+# ---- selector 45: the persistent 4-wave kernel in assembly (csrc/gen_fa3_fwd_p4.py) -----------------------------------------------
+P4_CASES = [
+    # B, H, Sq, Sk, causal, kv heads
+    (1, 8, 512, 512, True, 8),          # one unit per XCD: heavy block, light block, cross-item prefetch
+    (1, 8, 256, 256, False, 8),         # a single 4-tile item
+    (2, 4, 1024, 1024, True, 4),
+    (1, 3, 512, 512, True, 3),          # heads not a multiple of 8: linear workgroup -> unit map
+    (3, 5, 768, 640, False, 5),         # Sq != Sk
+    (1, 16, 2048, 2048, True, 4),       # grouped-query heads
+    (2, 16, 1024, 2304, False, 2),      # cross attention, long keys, GQA
+    (9, 32, 256, 384, False, 32),       # more units than workgroups
+]
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", P4_CASES)
+def test_p4_kernel_against_the_oracle_and_the_8_wave_kernel(case, dtype):
+    from oracle import fa3_oracle as orc
+    from photonic_flash_attention_amd import _capi, ops, synth
+    B, H, Sq, Sk, causal, Hkv = case
+    q, k, v = synth.qkv(B, H, Sq, Sk, 128, 4500 + Sq + H, dtype)
+    k, v = k[:, :, :Hkv].contiguous(), v[:, :, :Hkv].contiguous()
+    qd, kd, vd = (t.to("cuda:0").permute(0, 2, 1, 3) for t in (q, k, v))
+    o45, l45 = ops.fa3_forward(qd, kd, vd, causal=causal, return_lse=True, _variant=45)
+    o44, l44 = ops.fa3_forward(qd, kd, vd, causal=causal, return_lse=True, _variant=44)
+    torch.cuda.synchronize()
+    name = _capi.describe(ops.build_args(qd, kd, vd, o45, causal=causal, variant=45)[0])[0]
+    assert name.startswith("fa3_fwd_p4_"), name
+    assert bool(torch.isfinite(o45.float()).all())
+    assert float((o45.float() - o44.float()).abs().max()) <= float(o44.float().abs().max()) * 2.0 ** (-8 if dtype == "bf16" else -10)
+    assert float((l45 - l44).abs().max()) <= 2e-5
+    g = H // Hkv
+    ref = orc.attention_bshd(q, k.repeat_interleave(g, dim=2), v.repeat_interleave(g, dim=2), causal=causal)
+    assert _fast_ok(o45.permute(0, 2, 1, 3).float().cpu(), ref, _row_keys(Sq, Sk, causal, None, B), float(v.float().abs().max()), dtype,
+                    tag=f"p4 {case} {dtype}")
+    ref_lse = orc.lse_bshd(q, k.repeat_interleave(g, dim=2), causal=causal)
+    assert float((l45.cpu() - ref_lse).abs().max()) <= 2e-3
+
+
+def test_p4_kernel_reads_fused_qkv_views_and_is_the_default_for_long_aligned_problems():
+    from oracle import fa3_oracle as orc
+    from photonic_flash_attention_amd import _capi, ops, synth
+    B, S, H, D = 2, 2048, 8, 128
+    E = H * D
+    qkv = torch.from_numpy(synth.normal_f32((B, S, 3 * E), 77)).to("cuda:0", torch.bfloat16)
+    q, k, v = (t.view(B, S, H, D).transpose(1, 2) for t in qkv.chunk(3, dim=-1))          # strides (S*3E, D, 3E, 1)
+    out = torch.full((B, S, H, D), float("nan"), device="cuda:0", dtype=torch.bfloat16).permute(0, 2, 1, 3)
+    ops.fa3_forward(q, k, v, out=out)
+    torch.cuda.synchronize()
+    name = _capi.describe(ops.build_args(q, k, v, out, causal=False)[0])[0]
+    assert name.startswith("fa3_fwd_p4_bf16_d128_full"), name                             # picked without a selector
+    ref = orc.attention_bshd(*(t.transpose(1, 2).float().cpu().contiguous() for t in (q, k, v)))
+    assert _fast_ok(out.permute(0, 2, 1, 3).float().cpu(), ref, _row_keys(S, S, False, None, B), float(v.float().abs().max()))
+    # not eligible -> the HIP kernels: ragged lengths, masks, fp32 stores, short sequences
+    q2, k2, v2 = (t[:, :, :2000] for t in (q, k, v))
+    assert "p4" not in _capi.describe(ops.build_args(q2, k2, v2, out[:, :, :2000], causal=False)[0])[0]
+    o32 = torch.empty(B, S, H, D, device="cuda:0", dtype=torch.float32).permute(0, 2, 1, 3)
+    assert "p4" not in _capi.describe(ops.build_args(q, k, v, o32, causal=False, split_p=True)[0])[0]
+    assert "p4" not in _capi.describe(ops.build_args(q, k, v, out, causal=False, seqlens_k=[S, S - 1])[0])[0]
+
+
+def test_p4_kernel_random_eligible_shapes():
+    """30 random eligible problems against the 8-wave kernel (same formulas, other summation order)."""
+    import random
+    from photonic_flash_attention_amd import ops, synth
+    rnd = random.Random(4545)
+    for it in range(30):
+        causal = rnd.random() < 0.5
+        B, H = rnd.choice([(1, 1), (1, 8), (2, 3), (1, 24), (4, 8), (1, 40)])
+        if causal:
+            Sq = Sk = 512 * rnd.randint(1, 4)
+        else:
+            Sq, Sk = 256 * rnd.randint(1, 6), 128 * rnd.randint(2, 12)
+        dtype = rnd.choice(["bf16", "fp16"])
+        q, k, v = (t.to("cuda:0").permute(0, 2, 1, 3) for t in synth.qkv(B, H, Sq, Sk, 128, 12000 + it, dtype))
+        o0, l0 = ops.fa3_forward(q, k, v, causal=causal, return_lse=True, _variant=44)
+        o1, l1 = ops.fa3_forward(q, k, v, causal=causal, return_lse=True, _variant=45)
+        torch.cuda.synchronize()
+        tag = (it, B, H, Sq, Sk, causal, dtype)
+        assert bool(torch.isfinite(o1.float()).all()), tag
+        assert float((o0.float() - o1.float()).abs().max()) <= float(o0.float().abs().max()) * 2.0 ** (-8 if dtype == "bf16" else -10), tag
+        assert float((l0 - l1).abs().max()) <= 3e-5, tag
 
 
 def test_speedup_over_the_eager_tiled_loop_on_this_gpu():

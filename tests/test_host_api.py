@@ -76,6 +76,24 @@ def test_argument_validation_without_a_gpu(lib):
     assert _capi.status_string(-99) == "unknown pfa_status"
 
 
+def test_production_library_refuses_development_variants(lib):
+    """flags bits 8..15: 0 or one of the three production kernel selectors; the schedule experiments and the timing-only
+    ablations (which compute wrong answers on purpose) exist only in a `make DEV=1` library."""
+    for sel in (0, 43, 44, 45):
+        assert lib.pfa_fa3_check(C.byref(_args(flags=sel << 8))) == 0, sel
+    for var in (1, 9, 0x14, 19, 28, 30, 41, 42, 46, 49, 255):          # 0x14 << 8 = 0x1400
+        assert lib.pfa_fa3_check(C.byref(_args(flags=var << 8))) == -10, var
+    assert lib.pfa_fa3_check(C.byref(_args(flags=0x1400))) == -10
+
+
+def test_no_environment_variable_selects_a_kernel(monkeypatch):
+    """ops.fa3_forward must not read a kernel variant from the environment (only the explicit `_variant=` of tools / tests)."""
+    import inspect
+    from photonic_flash_attention_amd import ops
+    src = inspect.getsource(ops)
+    assert "os.environ" not in src and "PFA_VARIANT" not in src
+
+
 def test_describe_picks_kernel_variant(lib):
     name, nwg = _capi.describe(_args(D=128, causal=1, Sq=4096, Sk=4096, B=4, H=16, dtype_out=2, flags=1))
     assert "d128" in name and "o32" in name and nwg == 16 * 64
@@ -255,6 +273,21 @@ def test_convert_to_photonic_replaces_torch_mha(monkeypatch):
             got = conv(x, **kw)
             keep = ~pad if "src_key_padding_mask" in kw else torch.ones(2, 50, dtype=torch.bool)
             assert float((got - want)[keep].abs().max()) <= 2e-5, kw
+    # float masks: binary in effect (0 / -inf / finfo.min / -1e4) are translated, finite biases are refused -- never dropped silently
+    big = torch.zeros(50, 50)
+    big[:, 30:] = torch.finfo(torch.float32).min
+    soft = torch.zeros(50, 50)
+    soft[:, 30:] = -1e4
+    with torch.no_grad():
+        a = conv(x, src_mask=big)
+        b = conv(x, src_mask=soft)
+        assert float((a - layer(x, src_mask=big)).abs().max()) <= 2e-5 and torch.equal(a, b)
+        alibi = -0.5 * torch.arange(50.0)[None, :].expand(50, 50).contiguous()
+        with pytest.raises(ValueError, match="finite biases"):
+            conv(x, src_mask=alibi)
+    keep = TorchMHAReplacement._to_keep_mask(torch.tensor([[0.0, -1e4, float("-inf"), torch.finfo(torch.float32).min]]))
+    from photonic_flash_attention_amd.integration.pytorch import hf
+    assert keep.tolist() == [[True, False, False, False]] == hf._keep_mask(torch.tensor([[0.0, -1e4, float("-inf"), -3e38]])).tolist()
     # skipped layers are reported, strings are refused
     odd = nn.MultiheadAttention(768, 4)                              # head_dim 192 > 128: no kernel
     _, rep2 = convert_to_photonic(nn.Sequential(odd))

@@ -7,7 +7,7 @@ from photonic_flash_attention_amd import ops
 dev = torch.device("cuda:0")
 B, H, Sq, D = int(os.environ.get("B", "64")), 16, int(os.environ.get("SQ", "256")), int(os.environ.get("D", "128"))
 ROUNDS = B * H * ((Sq + 255) // 256) / 256.0          # workgroups per CU
-variant = int(os.environ.get("PFA_VARIANT", "0"))
+variant = int(sys.argv[1]) if len(sys.argv) > 1 else 0      # kernel selector 43 / 44 / 45
 rows = []
 for Sk in (64, 128, 256, 512, 1024, 2048, 4096):
     q = torch.randn(B, Sq, H, D, device=dev).to(torch.bfloat16).permute(0, 2, 1, 3)
