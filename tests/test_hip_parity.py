@@ -4,12 +4,13 @@
 Tolerances (DESIGN.md "numerics"):
   * PARITY variant (fp32 store, P as bf16 hi+lo):   max-abs <= 1e-3   (north_star bar)
   * FAST variant  (16-bit store, P as ONE 16-bit operand): the error is two roundings and nothing else, and the bound says so
-    per element:   |err| <= eps*|ref|  +  C_P * eps * max|v| / sqrt(n_row)  (+ 2e-6)
+    per element:   |err| <= eps*|ref|  +  C_P * eps * max|v| * ||p_row||_2  (+ 2e-6)
     eps = 2^-9 (bf16) / 2^-11 (fp16) = half an ulp; first term = the rounding of the stored output (absent with an fp32 store);
-    second term = the rounding of P before the PV product: n_row independent roundings of relative size eps, weights summing
-    to 1, so the sum shrinks as 1/sqrt(visible keys) -- C_P = 2 covers the 4.5-sigma tail over ~1e7 elements and the
-    concentration of softmax weights on N(0,1) scores (effective key count ~ n / e).  On a causal problem the first rows see
-    1..10 keys and sit at ~5e-3; from ~300 visible keys on the whole error is below 1e-3.
+    second term = the rounding of P before the PV product: one independent rounding of relative size <= eps per visible key,
+    weighted by the softmax weights p_j, so its standard deviation is eps/sqrt(3) * sqrt(sum_j p_j^2 v_j^2) <= eps/sqrt(3) *
+    max|v| * ||p||_2; C_P = 3 is the 5-sigma tail over ~1e7 elements.  ||p||_2 = 1/sqrt(n) for uniform weights over n keys
+    (~ sqrt(e/n) on N(0,1) scores) and up to ~0.7 for a row dominated by one key: the first rows of a causal problem (1..10
+    keys) sit at ~5e-3, rows with thousands of keys at ~3e-4.  ||p||_2 is computed here in fp32 from q and k.
 """
 
 from __future__ import annotations
@@ -38,26 +39,41 @@ def _run(q, k, v, **kw):
     return o.float().cpu(), (None if lse is None else lse.cpu())
 
 
-C_P = 2.0
+C_P = 3.0
 
 
-def _row_keys(Sq, Sk, causal, lens=None, B=1):
-    """visible keys of every query row, [B, Sq, 1, 1] (rows with none: 1, their output is exactly zero on both sides)"""
-    n = torch.full((B, Sq), float(Sk))
-    if lens is not None:
-        n = torch.minimum(n, torch.tensor([float(x) for x in lens])[:, None])
+def _pnorm(q, k, causal, lens=None, rows=None, heads=None):
+    """||p_row||_2 of the exact softmax, fp32 on the CPU: [B, Sq, H, 1] for [B,S,H,D] operands (K heads repeated for grouped-query
+    problems); `rows` / `heads` = [(b, h), ...] restrict it to sampled rows of a few heads -> [len(heads), len(rows), 1]."""
+    B, Sq, H, D = q.shape
+    Sk, g = k.shape[1], H // k.shape[2]
+    qf, kf = q.float(), k.float()
+    if heads is not None:
+        qf = torch.stack([qf[b, :, h] for b, h in heads])[:, None]            # [n, 1, Sq, D]
+        kf = torch.stack([kf[b, :, h // g] for b, h in heads])[:, None]
+        qf, kf = qf.permute(0, 2, 1, 3), kf.permute(0, 2, 1, 3)               # [n, Sq, 1, D]
+        g, lens = 1, None
+    if g > 1:
+        kf = kf.repeat_interleave(g, dim=2)
+    qi = torch.arange(Sq) if rows is None else rows
+    s = torch.einsum("bqhd,bkhd->bhqk", qf[:, qi], kf) * D ** -0.5
+    kj = torch.arange(Sk)
     if causal:
-        n = torch.minimum(n, torch.arange(1, Sq + 1, dtype=torch.float32)[None, :])
-    return n.clamp(min=1.0)[:, :, None, None]
+        s = s.masked_fill(kj[None, :] > qi[:, None], float("-inf"))
+    if lens is not None:
+        s = s.masked_fill(kj[None, None, None, :] >= torch.tensor(lens)[:, None, None, None], float("-inf"))
+    p = torch.softmax(s, dim=-1).nan_to_num(0.0)
+    pn = p.square().sum(-1).sqrt().permute(0, 2, 1)[..., None]                # [B, Sq', H, 1]
+    return pn[:, :, 0] if heads is not None else pn
 
 
-def _fast_bound(ref, nkeys, vmax, dtype="bf16", store16=True):
+def _fast_bound(ref, pnorm, vmax, dtype="bf16", store16=True):
     eps = 2.0 ** (-9 if dtype == "bf16" else -11)
-    return (ref.abs() * eps * 1.01 if store16 else 0.0) + C_P * eps * vmax / nkeys.sqrt() + 2e-6
+    return (ref.abs() * eps * 1.01 if store16 else 0.0) + C_P * eps * vmax * pnorm + 2e-6
 
 
-def _fast_ok(out, ref, nkeys, vmax, dtype="bf16", store16=True, tag=""):
-    err, bound = (out - ref).abs(), _fast_bound(ref, nkeys, vmax, dtype, store16)
+def _fast_ok(out, ref, pnorm, vmax, dtype="bf16", store16=True, tag=""):
+    err, bound = (out - ref).abs(), _fast_bound(ref, pnorm, vmax, dtype, store16)
     worst = float((err / bound).max())
     if tag:
         print(f"{tag}: max-abs {float(err.max()):.3e}, worst error/bound {worst:.2f}")
@@ -83,8 +99,8 @@ def test_golden_full(name):
     print(f"{name}: parity variant max-abs {err:.3e}")
     assert err <= PARITY_TOL
     out16, _ = _run(q, k, v, causal=meta["causal"], seqlens_k=lens)
-    nk = _row_keys(meta["Sq"], meta["Sk"], meta["causal"], lens, meta["B"])
-    assert _fast_ok(out16, ref, nk, float(v.float().abs().max()), meta["dtype"], tag=f"{name}: fast variant")
+    pn = _pnorm(q, k, meta["causal"], lens)
+    assert _fast_ok(out16, ref, pn, float(v.float().abs().max()), meta["dtype"], tag=f"{name}: fast variant")
 
 
 @pytest.mark.parametrize("name", golden_names("sampled"))
@@ -95,13 +111,13 @@ def test_golden_sampled_baseline_shapes(name):
     rows = torch.from_numpy(arr["rows"])
     out, _ = _run(q, k, v, causal=meta["causal"], out_dtype=torch.float32)
     out16, _ = _run(q, k, v, causal=meta["causal"])
+    pns = _pnorm(q, k, meta["causal"], rows=rows, heads=[tuple(x) for x in meta["heads"]])
     for i, (b, h) in enumerate(meta["heads"]):
         ref = torch.from_numpy(arr["out"][i])
         err = float((out[b, rows, h] - ref).abs().max())
         print(f"{name} head {(b, h)}: parity max-abs {err:.3e}; fast {float((out16[b, rows, h] - ref).abs().max()):.3e}")
         assert err <= PARITY_TOL
-        nk = _row_keys(meta["Sq"], meta["Sk"], meta["causal"])[0, rows, 0]          # [rows, 1]
-        assert _fast_ok(out16[b, rows, h], ref, nk, float(v.float().abs().max()), meta["dtype"])
+        assert _fast_ok(out16[b, rows, h], ref, pns[i], float(v.float().abs().max()), meta["dtype"])
         hs = float(out[b, :, h].double().sum())
         assert abs(hs - arr["head_sum"][i]) <= 2e-5 * arr["head_abs_sum"][i] + 1e-2
 
@@ -134,15 +150,15 @@ def test_vs_oracle(case, dtype):
     ref_lse = orc.lse_bshd(q, k, causal=causal, seqlens_k=lens)
     assert float((lse - ref_lse).abs().max()) <= 2e-3
     out16, _ = _run(q, k, v, causal=causal, seqlens_k=lens)
-    assert _fast_ok(out16, ref, _row_keys(Sq, Sk, causal, lens, B), float(v.float().abs().max()), dtype)
+    assert _fast_ok(out16, ref, _pnorm(q, k, causal, lens), float(v.float().abs().max()), dtype)
 
 
 @pytest.mark.parametrize("name", ["g6_c3", "g6_c5"])
 def test_single_p_error_is_p_rounding_and_store_rounding_only(name):
     """The benched schedule's 7e-3 on a causal problem, taken apart against the REFERENCE's own outputs (sampled rows of the
     C3 / C5 goldens): with an fp32 store and ONE 16-bit P operand the only rounding left is P's, and it obeys the per-row bound
-    C_P * 2^-9 * max|v| / sqrt(visible keys) on every row -- below 1e-3 from a few hundred visible keys on; the 16-bit store adds
-    its half ulp, 2^-9 |o|, and nothing else."""
+    C_P * 2^-9 * max|v| * ||p_row||_2 on every row -- below 1e-3 wherever that bound is (rows with many comparable keys); the
+    16-bit store adds its half ulp, 2^-9 |o|, and nothing else."""
     matches = [n for n in golden_names("sampled") if n.startswith(name)]
     assert matches, "sampled golden missing"
     meta, arr = load_golden(matches[0])
@@ -151,13 +167,13 @@ def test_single_p_error_is_p_rounding_and_store_rounding_only(name):
     vmax = float(v.float().abs().max())
     o32, _ = _run(q, k, v, causal=meta["causal"], out_dtype=torch.float32, split_p=False)       # single P, fp32 store
     o16, _ = _run(q, k, v, causal=meta["causal"])                                                # the benched kernel
-    nk = _row_keys(meta["Sq"], meta["Sk"], meta["causal"])[0, rows, 0]
-    n_1e3 = (C_P * 2.0 ** -9 * vmax / 1e-3) ** 2                    # visible keys from which the P-rounding bound itself is < 1e-3
+    pns = _pnorm(q, k, meta["causal"], rows=rows, heads=[tuple(x) for x in meta["heads"]])
     for i, (b, h) in enumerate(meta["heads"]):
         ref = torch.from_numpy(arr["out"][i])
-        assert _fast_ok(o32[b, rows, h], ref, nk, vmax, store16=False, tag=f"{matches[0]} head {(b, h)} single P, fp32 store")
-        assert _fast_ok(o16[b, rows, h], ref, nk, vmax, store16=True, tag=f"{matches[0]} head {(b, h)} benched kernel")
-        late = nk[:, 0] >= n_1e3
+        assert _fast_ok(o32[b, rows, h], ref, pns[i], vmax, store16=False, tag=f"{matches[0]} head {(b, h)} single P, fp32 store")
+        assert _fast_ok(o16[b, rows, h], ref, pns[i], vmax, store16=True, tag=f"{matches[0]} head {(b, h)} benched kernel")
+        late = (C_P * 2.0 ** -9 * vmax * pns[i][:, 0]) <= 1e-3      # rows whose P-rounding bound itself is below the north-star bar
+        print(f"   rows with the bound <= 1e-3: {int(late.sum())} of {late.numel()} sampled (first at row {int(rows[late].min()) if bool(late.any()) else -1})")
         assert bool(late.any()) and float((o32[b, rows, h] - ref)[late].abs().max()) <= 1e-3
         # the store rounding alone: the 16-bit result is the fp32-store result rounded once
         assert float((o16[b, rows, h] - o32[b, rows, h]).abs().max()) <= float(ref.abs().max()) * 2.0 ** -8 + 1e-6
@@ -387,7 +403,7 @@ def test_p4_kernel_against_the_oracle_and_the_8_wave_kernel(case, dtype):
     assert float((l45 - l44).abs().max()) <= 2e-5
     g = H // Hkv
     ref = orc.attention_bshd(q, k.repeat_interleave(g, dim=2), v.repeat_interleave(g, dim=2), causal=causal)
-    assert _fast_ok(o45.permute(0, 2, 1, 3).float().cpu(), ref, _row_keys(Sq, Sk, causal, None, B), float(v.float().abs().max()), dtype,
+    assert _fast_ok(o45.permute(0, 2, 1, 3).float().cpu(), ref, _pnorm(q, k, causal), float(v.float().abs().max()), dtype,
                     tag=f"p4 {case} {dtype}")
     ref_lse = orc.lse_bshd(q, k.repeat_interleave(g, dim=2), causal=causal)
     assert float((l45.cpu() - ref_lse).abs().max()) <= 2e-3
@@ -405,8 +421,9 @@ def test_p4_kernel_reads_fused_qkv_views_and_is_the_default_for_long_aligned_pro
     torch.cuda.synchronize()
     name = _capi.describe(ops.build_args(q, k, v, out, causal=False)[0])[0]
     assert name.startswith("fa3_fwd_p4_bf16_d128_full"), name                             # picked without a selector
-    ref = orc.attention_bshd(*(t.transpose(1, 2).float().cpu().contiguous() for t in (q, k, v)))
-    assert _fast_ok(out.permute(0, 2, 1, 3).float().cpu(), ref, _row_keys(S, S, False, None, B), float(v.float().abs().max()))
+    qc, kc, vc = (t.transpose(1, 2).float().cpu().contiguous() for t in (q, k, v))
+    ref = orc.attention_bshd(qc, kc, vc)
+    assert _fast_ok(out.permute(0, 2, 1, 3).float().cpu(), ref, _pnorm(qc, kc, False), float(v.float().abs().max()))
     # not eligible -> the HIP kernels: ragged lengths, masks, fp32 stores, short sequences
     q2, k2, v2 = (t[:, :, :2000] for t in (q, k, v))
     assert "p4" not in _capi.describe(ops.build_args(q2, k2, v2, out[:, :, :2000], causal=False)[0])[0]
