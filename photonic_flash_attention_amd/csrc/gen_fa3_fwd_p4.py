@@ -85,6 +85,10 @@ def PD(X, i):
     return 144 + (0 if X == 'A' else 16) + i
 
 
+def PDL(X, i):              # split P: the low halves (the VGPRs the 4-deep fragment rings would use)
+    return 176 + (0 if X == 'A' else 16) + i
+
+
 RING = int(os.environ.get("P4_RING", "8"))          # K / V^T fragment rings: 4 (VGPRs) or 8 (the spare accumulator registers a[192:255])
 KFR = lambda i: (192 + 4 * (i % 8)) if RING == 8 else (176 + 4 * (i % 4))
 VFR = lambda i: (224 + 4 * (i % 8)) if RING == 8 else (192 + 4 * (i % 4))
@@ -150,11 +154,14 @@ class Lgkm:
 
 
 class Gen:
-    def __init__(self, dtype, causal, out32=False):
-        self.dt, self.causal, self.out32 = dtype, causal, out32
+    def __init__(self, dtype, causal, out32=False, split=False):
+        """out32: fp32 store (straight from the accumulators); split: P enters the PV product as a 16-bit hi + lo pair (two MFMAs per
+        fragment, P's rounding error 2^-18 instead of 2^-9): together the <= 1e-3 parity variant on the benched schedule."""
+        assert out32 == split, "the code object carries the fast variant (16-bit store, one P) and the parity variant (fp32 store, split P)"
+        self.dt, self.causal, self.out32, self.split = dtype, causal, out32, split
         self.mf = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
-        self.name = f"fa3_fwd_p4_{dtype}_{'causal' if causal else 'full'}_{'o32' if out32 else 'o16'}"
+        self.name = f"fa3_fwd_p4_{dtype}_{'causal' if causal else 'full'}_{'splitp_o32' if out32 else 'o16'}"
         self.main, self.ool = [], []
         self.L = self.main
         self.abl_on = False
@@ -200,6 +207,8 @@ class Gen:
         if not STAMP or (fine and STAMP == 2):
             return
         assert RING == 8, "stamps live in the VGPRs the 4-deep rings use"
+        if self.split:
+            return                             # ... and so do the low halves of a split P: the parity variant carries no stamps
         t2 = vr(V_E[14])
         self.i("s_memtime s[58:59]")
         self.i("s_waitcnt lgkmcnt(0)")
@@ -276,6 +285,18 @@ class Gen:
         c0 = lambda k: vr(SBUF(buf, X, 0, k))
         mc, ps0, l = vr(STV(X, 'mc')), vr(STV(X, 'ps0')), vr(STV(X, 'l'))
         fma = lambda e: f"v_fma_f32 {c1(e)}, {c1(e)}, {ka('scale_log2')}, -{mc}"
+
+        def pack(i, x0, x1):
+            """P dword i = the pair (x0, x1) in 16 bits; split P: also the pair of what the rounding left behind"""
+            r = [f"{self.cvt} {vr(PD(X, i))}, {x0}, {x1}"]
+            if self.split:
+                t0, t1, hi = vr(V_T[2]), vr(V_T[3]), vr(PD(X, i))
+                if self.dt == "bf16":
+                    r += [f"v_lshlrev_b32 {t0}, 16, {hi}", f"v_and_b32 {t1}, 0xffff0000, {hi}"]
+                else:
+                    r += [f"v_cvt_f32_f16 {t0}, {hi}", f"v_cvt_f32_f16_sdwa {t1}, {hi} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"]
+                r += [f"v_sub_f32 {t0}, {x0}, {t0}", f"v_sub_f32 {t1}, {x1}, {t1}", f"{self.cvt} {vr(PDL(X, i))}, {t0}, {t1}"]
+            return r
         o = [fma(0)]
         for e in range(16):
             if e < 15:
@@ -284,13 +305,13 @@ class Gen:
             if e == 0:
                 o.append(f"v_add_f32 {ps0}, {ps0}, {c0(15)}")      # left over from the start (its sums lag by one element)
             if e % 2 == 0:
-                o.append(f"{self.cvt} {vr(PD(X, e // 2))}, {c0(e)}, {c0(e + 1)}")
+                o += pack(e // 2, c0(e), c0(e + 1))
             elif e >= 3:
-                o.append(f"{self.cvt} {vr(PD(X, 8 + (e - 3) // 2))}, {c1(e - 3)}, {c1(e - 2)}")
+                o += pack(8 + (e - 3) // 2, c1(e - 3), c1(e - 2))
             if e >= 3:
                 o.append(f"v_add_f32 {vr(V_PS1)}, {vr(V_PS1)}, {c1(e - 3)}")
         o.append(f"v_add_f32 {vr(V_PS1)}, {vr(V_PS1)}, {c1(13)}")
-        o.append(f"{self.cvt} {vr(PD(X, 15))}, {c1(14)}, {c1(15)}")
+        o += pack(15, c1(14), c1(15))
         o.append(f"v_add_f32 {l}, {l}, {ps0}")
         o.append(f"v_add_f32 {vr(V_PS1)}, {vr(V_PS1)}, {c1(14)}")
         o.append(f"v_mov_b32 {ps0}, 0")
@@ -359,10 +380,10 @@ class Gen:
         acc = vr(SBUF(buf, X, kb, 0), 16)
         return f"{self.mf} {acc}, {fr(KFR(i), 4)}, {ar(QA(X, ks), 4)}, {'0' if ks == 0 else acc}"
 
-    def pv_mfma(self, X, idx):
+    def pv_mfma(self, X, idx, lo=False):
         f, db = idx // 4, idx % 4
         acc = ar(OA(X, db), 16)
-        return f"{self.mf} {acc}, {fr(VFR(idx), 4)}, {vr(PD(X, 4 * f), 4)}, {acc}"
+        return f"{self.mf} {acc}, {fr(VFR(idx), 4)}, {vr((PDL if lo else PD)(X, 4 * f), 4)}, {acc}"
 
     # ---- phases ----------------------------------------------------------------------------------------------------------
     def phase_qk(self, p, fillers, dma_at, lg=None, pre=(), tail_vreads=None):
@@ -394,8 +415,9 @@ class Gen:
             self.emit(fillers[hs])
         return lg
 
-    def phase_pv(self, p, fillers, dma_at, strips="AB", lg=None, preissued=False):
-        """PV(j): P dwords x V slot p -> O; fillers as above."""
+    def phase_pv(self, p, fillers, dma_at, strips="AB", lg=None, preissued=False, rec=None):
+        """PV(j): P dwords x V slot p -> O; one gap per MFMA (split P: a fragment feeds the hi pass of every strip, then the lo pass);
+        fillers as above.  rec (dry run): gets the issue cycles of every gap's fixed content instead of emitting fillers."""
         slot = p
         lg = lg or Lgkm()
         if not preissued:
@@ -404,22 +426,39 @@ class Gen:
                     self.i(x)
                     lg.issue(('v', idx, k))
         hs = 0
+        passes = [(X, lo) for lo in ((False, True) if self.split else (False,)) for X in strips]
         for idx in range(16):
-            if idx % 2 == 0:
-                w = lg.need([('v', idx, 1), ('v', idx + 1, 1)])
-                if w:
-                    self.i(w)
-            for X in strips:
-                self.i(self.pv_mfma(X, idx))
-                if X == strips[-1] and idx % 2 == 1:
+            for n, (X, lo) in enumerate(passes):
+                mark = len(self.L)
+                if n == 0 and idx % 2 == 0:
+                    w = lg.need([('v', idx, 1), ('v', idx + 1, 1)])
+                    if w:
+                        self.i(w)
+                self.i(self.pv_mfma(X, idx, lo))
+                if n == len(passes) - 1 and idx % 2 == 1:
                     for f in (idx + RING - 1, idx + RING):
                         if f < 16:
                             for k, x in enumerate(self.vread(slot, f)):
                                 self.i(x)
                                 lg.issue(('v', f, k))
                 self.emit(dma_at.get(hs, []))
-                self.emit(fillers[hs] if hs < len(fillers) else [])
+                if rec is not None:
+                    rec.append(sum(self.price(x.strip()) for x in self.L[mark:] if not x.strip().startswith("v_mfma")))
+                else:
+                    self.emit(fillers[hs] if hs < len(fillers) else [])
                 hs += 1
+        return lg
+
+    def run_phase(self, fn, stream, lg, **kw):
+        """Dry-run the phase to learn each gap's fixed issue cycles, slice `stream` over the gaps around them, emit; -> lg"""
+        import copy
+        save, uid = self.L, self.uid
+        self.L, rec = [], []
+        fn(fillers=None, lg=copy.deepcopy(lg), rec=rec, **kw)
+        self.L, self.uid = save, uid
+        fillers, tail = self.pack(stream, rec, ngaps=len(rec))
+        lg = fn(fillers=fillers, lg=lg, **kw)
+        self.emit(tail)
         return lg
 
     # ---- DMA stream bookkeeping (top and bottom of every iteration, all body kinds; workgroup-uniform) -----------------------------
@@ -568,18 +607,7 @@ class Gen:
             self.out_of_line(False)
         # ---- phase B: the start of both strips, same treatment
         sta = self.start_stream('A', 1 - p) + self.start_stream('B', 1 - p)
-        fixed = []
-        for hs in range(32):
-            idx = hs // 2
-            f = 0
-            if hs % 2 == 1 and idx % 2 == 1 and idx + RING - 1 < 16:
-                f += 4 * self.price("ds_read")
-            if hs % 2 == 1 and idx % 2 == 1 and idx + 1 < 16:
-                f += 4
-            fixed.append(f)
-        fb, tail = self.pack(sta, fixed)
-        self.phase_pv(p, fb, {}, lg=lg, preissued=True)
-        self.emit(tail)
+        self.run_phase(self.phase_pv, sta, lg, p=p, dma_at={}, preissued=True)
         self.abl_on = False
         self.stamp(1, count=7)
         # pending O rescale (rare: defer-max)
@@ -599,11 +627,9 @@ class Gen:
         d = self.dma_plan(p, [0, 2, 4, 6], [8, 10, 12, 14])
         self.emit(self.finish_stream('A', p))
         self.i("s_nop 1")
-        fb, tail = self.pack(self.finish_stream('B', p), [0] * 16, ngaps=16)
-        self.phase_pv(p, fb, d, strips="A")
-        self.emit(tail)
+        self.run_phase(self.phase_pv, self.finish_stream('B', p), Lgkm(), p=p, dma_at=d, strips="A")
         self.i("s_nop 1")
-        self.phase_pv(p, [[] for _ in range(16)], {}, strips="B")
+        self.phase_pv(p, [[] for _ in range(32)], {}, strips="B")
         self.stamp(5)
 
     def body_skip(self, p):
@@ -768,7 +794,8 @@ class Gen:
     def item_prologue(self):
         """Q fragments out of the landing zone into the accumulator file, state, QK^T(0) (O zeroed in its shadow), softmax start(0)."""
         self.cm("item prologue")
-        self.i("s_waitcnt vmcnt(16)")         # this item's Q pieces: everything but the previous item's 16 output stores (issued after them)
+        # this item's Q pieces: everything but the previous item's output stores (issued after them: 16, or 32 of the fp32 epilogue)
+        self.i(f"s_waitcnt vmcnt({32 if self.out32 else 16})")
         qb = V_E[0:8]        # per-lane addresses of the Q fragments (recomputed per item: nothing lane-constant is kept live for it)
         T0, T1, T2 = (vr(x) for x in V_T[0:3])
         # address = qland + r * 256 + (((2 ks + h) ^ (r & 15)) << 4)  =  rowbase ^ (32 ks),  qland = Q_BASE + wave * 16384
@@ -821,6 +848,8 @@ class Gen:
         self.cm("item epilogue")
         self.i("s_nop 15")
         self.i("s_nop 15")                    # last MFMA -> v_accvgpr_read
+        if self.out32:
+            return self.item_epilogue_f32()
         vb, rb = V_E[8], V_E[9:13]            # staging write base, read-back bases
         inv, lt, t = V_E[13], V_E[14], V_E[15]
         L, T0, T1, T2, T3 = vr(V_LANE), *(vr(x) for x in V_T)
@@ -909,6 +938,58 @@ class Gen:
                     self.i(f"s_add_u32 {S('t0')}, {S('t0')}, {S('t1')}")
         self.i(f"v_mov_b32 {vr(V_PS1)}, 0")
 
+    def item_epilogue_f32(self):
+        """Parity variant: normalise and store fp32 straight from the accumulators (a lane holds 4 consecutive columns of its row per
+        register quad: one 16-byte store each); LSE as in the 16-bit epilogue."""
+        inv, lt, t = V_E[13], V_E[14], V_E[15]
+        L, T0, T1, T2, T3 = vr(V_LANE), *(vr(x) for x in V_T)
+        gofs = V_PS1
+        self.i(f"v_and_b32 {T0}, 31, {L}")                                          # r
+        self.i(f"v_lshrrev_b32 {T1}, 5, {L}")                                       # h
+        self.i(f"v_mul_lo_u32 {vr(gofs)}, {T0}, {ka('o_ss')}")
+        self.i(f"v_lshl_add_u32 {vr(gofs)}, {T1}, 4, {vr(gofs)}")                   # r * o_ss + 16 h
+        self.i(f"s_lshr_b32 {S('t1')}, {S('w4k')}, 4")
+        self.i(f"v_lshlrev_b32 {T3}, 2, {T0}")
+        self.i(f"v_add_u32 {T3}, {S('t1')}, {T3}")                                  # LSE offset (64 wave + r) * 4
+        self.i(f"s_lshr_b32 {S('t1')}, {S('w4k')}, 6")                              # 64 wave
+        self.i(f"s_mul_i32 {S('t1')}, {S('t1')}, {ka('o_ss')}")                     # the wave's first output row
+        for X in "AB":
+            l, mc = vr(STV(X, 'l')), vr(STV(X, 'mc'))
+            self.i(f"v_mov_b32 {vr(t)}, {l}")
+            self.i("s_nop 1")
+            self.i(f"v_permlane32_swap_b32 {l}, {vr(t)}")
+            self.i(f"v_add_f32 {vr(lt)}, {l}, {vr(t)}")
+            self.i(f"v_rcp_f32 {vr(inv)}, {vr(lt)}")
+            self.i(f"v_cmp_lt_f32 vcc, 0, {vr(lt)}")
+            self.i("s_nop 1")
+            self.i(f"v_cndmask_b32 {vr(inv)}, 0, {vr(inv)}, vcc")
+            if X == 'B':
+                self.i(f"s_lshl_b32 {S('t0')}, {ka('o_ss')}, 5")
+                self.i(f"s_add_u32 {S('t1')}, {S('t1')}, {S('t0')}")                # strip B: 32 rows further
+            n = 0
+            for db in range(4):
+                for g in range(4):
+                    w = V_E[4 * (n & 1):4 * (n & 1) + 4]     # two register quads in turn: a store's data is not overwritten right behind it
+                    n += 1
+                    for k in range(4):
+                        self.i(f"v_accvgpr_read_b32 {vr(w[k])}, a{OA(X, db, 4 * g + k)}")
+                    for k in range(4):
+                        self.i(f"v_mul_f32 {vr(w[k])}, {vr(w[k])}, {vr(inv)}")
+                    self.i(f"buffer_store_dwordx4 {vr(w[0], 4)}, {vr(gofs)}, {S('osrd')}, {S('t1')} offen offset:{128 * db + 32 * g}")
+            self.i(f"v_log_f32 {vr(t)}, {vr(lt)}")
+            self.i(f"v_mov_b32 {vr(inv)}, {NEG_INF}")
+            self.i(f"v_add_f32 {vr(t)}, {vr(t)}, {mc}")
+            self.i(f"v_mul_f32 {vr(t)}, 0x3f317218, {vr(t)}")
+            self.i(f"v_cndmask_b32 {vr(t)}, {vr(inv)}, {vr(t)}, vcc")
+            ll = self.ul("nolse")
+            self.i(f"s_cmp_eq_u64 {ka('lse', 2)}, 0")
+            self.i(f"s_cbranch_scc1 {ll}")
+            self.i("s_mov_b32 exec_hi, 0")
+            self.i(f"buffer_store_dword {vr(t)}, {T3}, {S('lsrd')}, 0 offen offset:{0 if X == 'A' else 128}")
+            self.i("s_mov_b32 exec_hi, -1")
+            self.lab(ll)
+        self.i(f"v_mov_b32 {vr(V_PS1)}, 0")
+
     # ---- the kernel --------------------------------------------------------------------------------------------------------------
     def kernel(self):
         n = self.name
@@ -941,7 +1022,7 @@ class Gen:
                 self.i(f"s_mul_i32 {S('t0')}, {S('t0')}, {ka(ss)}")
             else:
                 self.i(f"s_mul_i32 {S('t0')}, {ka(ss)}, 255")
-            self.i(f"s_add_u32 {S(sr, 2)}, {S('t0')}, 256")
+            self.i(f"s_add_u32 {S(sr, 2)}, {S('t0')}, {512 if (sr == 'osrd' and self.out32) else 256}")
             self.i(f"s_mov_b32 {S(sr, 3)}, 0x00020000")
         self.i(f"s_mov_b32 {S('lsrd', 2)}, 1024")
         self.i(f"s_mov_b32 {S('lsrd', 3)}, 0x00020000")
@@ -1163,7 +1244,8 @@ class Gen:
 
 
 def kernels():
-    return [(dt, causal) for dt in ("bf16", "fp16") for causal in (True, False)]
+    """(dtype, causal, parity): parity = fp32 store + split P (the <= 1e-3 variant on the same schedule)"""
+    return [(dt, causal, par) for dt in ("bf16", "fp16") for causal in (True, False) for par in (False, True)]
 
 
 def main():
@@ -1175,8 +1257,8 @@ def main():
         return
     out = ['\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', "\t.amdhsa_code_object_version 6", "\t.text"]
     meta = []
-    for dt, causal in kernels():
-        g = Gen(dt, causal)
+    for dt, causal, par in kernels():
+        g = Gen(dt, causal, out32=par, split=par)
         g.kernel()
         out += g.main
         out.append(g.descriptor())

@@ -407,6 +407,13 @@ def test_p4_kernel_against_the_oracle_and_the_8_wave_kernel(case, dtype):
                     tag=f"p4 {case} {dtype}")
     ref_lse = orc.lse_bshd(q, k.repeat_interleave(g, dim=2), causal=causal)
     assert float((l45.cpu() - ref_lse).abs().max()) <= 2e-3
+    # the parity variant of the same schedule (fp32 store + split P): the north-star tolerance against the oracle
+    p45, _ = ops.fa3_forward(qd, kd, vd, causal=causal, out_dtype=torch.float32, _variant=45)
+    p44, _ = ops.fa3_forward(qd, kd, vd, causal=causal, out_dtype=torch.float32, _variant=44)
+    torch.cuda.synchronize()
+    assert "splitp_o32" in _capi.describe(ops.build_args(qd, kd, vd, p45, causal=causal, split_p=True, variant=45)[0])[0]
+    err = float((p45.permute(0, 2, 1, 3).cpu() - ref).abs().max())
+    assert err <= PARITY_TOL and float((p45 - p44).abs().max()) <= 3e-5, (case, dtype, err)
 
 
 def test_p4_kernel_reads_fused_qkv_views_and_is_the_default_for_long_aligned_problems():
@@ -428,7 +435,8 @@ def test_p4_kernel_reads_fused_qkv_views_and_is_the_default_for_long_aligned_pro
     q2, k2, v2 = (t[:, :, :2000] for t in (q, k, v))
     assert "p4" not in _capi.describe(ops.build_args(q2, k2, v2, out[:, :, :2000], causal=False)[0])[0]
     o32 = torch.empty(B, S, H, D, device="cuda:0", dtype=torch.float32).permute(0, 2, 1, 3)
-    assert "p4" not in _capi.describe(ops.build_args(q, k, v, o32, causal=False, split_p=True)[0])[0]
+    assert _capi.describe(ops.build_args(q, k, v, o32, causal=False, split_p=True)[0])[0] == "fa3_fwd_p4_bf16_d128_full_splitp_o32"
+    assert "p4" not in _capi.describe(ops.build_args(q, k, v, o32, causal=False, split_p=False)[0])[0]      # fp32 store, one P: HIP kernel
     assert "p4" not in _capi.describe(ops.build_args(q, k, v, out, causal=False, seqlens_k=[S, S - 1])[0])[0]
 
 

@@ -35,9 +35,20 @@ for (B, H, S, causal) in SHAPES[a.shapes]:
     nan_o = int(torch.isnan(res[45][0]).sum())
     mo, ml = float(d_o.nan_to_num(1e9).max()), float(d_l.nan_to_num(1e9).max())
     ok = nan_o == 0 and mo <= 2e-2 and ml <= 1e-4
-    bad += 0 if ok else 1
+    # the parity variant (fp32 store + split P) on the same schedule
+    r32 = {}
+    for var in (44, 45):
+        o32 = torch.full((B, S, H, 128), float("nan"), device=dev, dtype=torch.float32).permute(0, 2, 1, 3)
+        o, lse = ops.fa3_forward(qv, kv, vv, causal=causal, out=o32, out_dtype=torch.float32, return_lse=True, _variant=var)
+        torch.cuda.synchronize()
+        r32[var] = (o.clone(), lse.clone())
+    n32 = _capi.describe(ops.build_args(qv, kv, vv, o32, causal=causal, split_p=True, variant=45)[0])[0]
+    m32 = float((r32[45][0] - r32[44][0]).abs().nan_to_num(1e9).max())
+    l32 = float((r32[45][1] - r32[44][1]).abs().nan_to_num(1e9).max())
+    ok = ok and m32 <= 3e-5 and l32 <= 1e-4 and "splitp_o32" in n32
     print(f"B{B} H{H} S{S} {'causal' if causal else 'full  '} {name[0]} wg={name[1]}: max|dO| {mo:.3e}  max|dLSE| {ml:.3e}  nan {nan_o}  "
-          f"frac(dO>1e-2) {float((d_o > 1e-2).float().mean()):.2e}  {'ok' if ok else 'MISMATCH'}", flush=True)
+          f"frac(dO>1e-2) {float((d_o > 1e-2).float().mean()):.2e} | {n32}: max|dO32| {m32:.3e} max|dLSE| {l32:.3e}  {'ok' if ok else 'MISMATCH'}", flush=True)
+    bad += 0 if ok else 1
     if not ok:
         # where: per (b, h, 64-row block) max error
         e = d_o.nan_to_num(1e9).amax(dim=-1)             # [B,H,S]
