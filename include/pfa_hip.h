@@ -60,7 +60,7 @@ typedef enum pfa_status {
 typedef enum pfa_dtype {
     PFA_DTYPE_BF16 = 0,
     PFA_DTYPE_FP16 = 1,
-    PFA_DTYPE_FP32 = 2          /* output only */
+    PFA_DTYPE_FP32 = 2          /* output of the 16-bit kernels; as dtype_in: the EXACT fp32 kernel (fp32 modules, slow) */
 } pfa_dtype;
 
 /* flags */
@@ -94,7 +94,7 @@ typedef struct pfa_fa3_args {
     int64_t key_mask_stride_b;  /* bytes between batches of key_mask                 */
 
     int32_t B, H, Sq, Sk, D;
-    int32_t dtype_in;           /* PFA_DTYPE_BF16 | PFA_DTYPE_FP16                   */
+    int32_t dtype_in;           /* PFA_DTYPE_BF16 | PFA_DTYPE_FP16 | PFA_DTYPE_FP32 (exact fp32 kernel: strides multiples of 4 elements, dtype_out fp32, no flags) */
     int32_t dtype_out;          /* = dtype_in, or PFA_DTYPE_FP32                     */
     int32_t causal;             /* 1: key j visible to row i iff j <= i (top-left)   */
     float   softmax_scale;      /* usually D^-0.5                                    */

@@ -41,8 +41,18 @@ class FlashAttention3(nn.Module):
         bias: bool = True,
         device: Optional[torch.device] = None,
         dtype: Optional[torch.dtype] = None,
+        fp32_attention: str = "exact",
     ):
+        """``fp32_attention`` (not in the reference; only matters for fp32 modules, the reference's default dtype): "exact" runs the
+        attention core of an fp32 module in fp32 on the vector ALUs -- the reference's numbers to ~1e-6, at a few TFLOP/s -- and is
+        the default, so that nothing is rounded behind the caller's back; "bf16" rounds q, k, v to bf16 and takes the MFMA kernels
+        (about 1e-2 from the fp32 reference at the module output, two orders of magnitude faster).  Under autograd the gradients of an
+        fp32 module are always computed by the bf16 forward / backward pair (a warning says so once)."""
         super().__init__()
+        if fp32_attention not in ("exact", "bf16"):
+            raise ValueError('fp32_attention must be "exact" or "bf16"')
+        self.fp32_attention = fp32_attention
+        self._warned_fp32_grad = False
         self.embed_dim = embed_dim
         self.num_heads = num_heads
         self.dropout = dropout
@@ -54,7 +64,7 @@ class FlashAttention3(nn.Module):
         self.out_proj = nn.Linear(embed_dim, embed_dim, bias=bias, device=device, dtype=dtype)
         self.dropout_module = nn.Dropout(dropout) if dropout > 0 else None
 
-        # fp32 modules compute attention in this dtype (MFMA has no fast fp32 path on gfx950)
+        # fp32 modules with fp32_attention="bf16", and every fp32 module under autograd, compute attention in this dtype
         self.compute_dtype = torch.bfloat16
         self.last_latency_ms = 0.0
         self.last_memory_mb = 0.0
@@ -150,6 +160,11 @@ class FlashAttention3(nn.Module):
             # default of the nn.MultiheadAttention-shaped facade) gets the softmax matrix from the second pass on the saved
             # LSE, DETACHED: the gradient flows through the output only.
             cd = self.compute_dtype if q.dtype == torch.float32 else q.dtype
+            if q.dtype == torch.float32 and self.fp32_attention == "exact" and not self._warned_fp32_grad:
+                import warnings
+                warnings.warn("FlashAttention3: gradients of an fp32 module are computed from bf16-rounded q, k, v (the backward kernels "
+                              "are MFMA only); the forward under torch.no_grad() stays exact fp32", stacklevel=3)
+                self._warned_fp32_grad = True
             res = ops.fa3_attention(q.to(cd), k.to(cd), v.to(cd), causal=is_causal, key_mask=key_mask, mask=mask,
                                     softmax_scale=self.scaling, out_dtype=q.dtype, return_weights=need_weights,
                                     weights_dtype=torch.float32 if q.dtype == torch.float32 else None)
@@ -157,6 +172,15 @@ class FlashAttention3(nn.Module):
 
         kw = dict(causal=is_causal, key_mask=key_mask, mask=mask, softmax_scale=self.scaling,
                   return_weights=need_weights)
+        if q.dtype == torch.float32 and self.fp32_attention == "exact":
+            kw.pop("return_weights")
+            out, _ = ops.fa3_forward(q, k, v, **kw)                            # exact fp32 core
+            w = None
+            if need_weights:                                                  # the softmax matrix: a 16-bit pass of its own
+                cd = self.compute_dtype
+                w = ops.fa3_forward(q.to(cd), k.to(cd), v.to(cd), out_dtype=torch.float32, weights_dtype=torch.float32,
+                                    return_weights=True, **kw)[2]
+            return out, w
         if q.dtype == torch.float32:
             cd = self.compute_dtype
             res = ops.fa3_forward(q.to(cd), k.to(cd), v.to(cd), out_dtype=torch.float32,

@@ -14,6 +14,7 @@
 #include "fa3_fwd_stagger_kernel.h"
 #endif
 #include "fa3_weights_kernel.h"
+#include "fa3_fwd_f32_kernel.h"
 #include "pfa_p4.h"
 
 namespace pfa { const void* w4_kernel(int dtype, bool causal, bool out32); }   // pfa_w4.hip
@@ -212,8 +213,21 @@ int check(const pfa_fa3_args* a) {
     if (a->kv_group < 0 || a->reserved0 != 0 || (a->kv_group > 1 && a->H % a->kv_group != 0)) return PFA_ERR_SHAPE;
     if (a->B <= 0 || a->H <= 0 || a->Sq <= 0 || a->Sk <= 0) return PFA_ERR_SHAPE;
     if (a->D != 64 && a->D != 128) return PFA_ERR_HEAD_DIM;
-    if (a->dtype_in != PFA_DTYPE_BF16 && a->dtype_in != PFA_DTYPE_FP16) return PFA_ERR_DTYPE;
+    if (a->dtype_in != PFA_DTYPE_BF16 && a->dtype_in != PFA_DTYPE_FP16 && a->dtype_in != PFA_DTYPE_FP32) return PFA_ERR_DTYPE;
     if (a->dtype_out != a->dtype_in && a->dtype_out != PFA_DTYPE_FP32) return PFA_ERR_DTYPE;
+    if (a->dtype_in == PFA_DTYPE_FP32) {       // the exact fp32 kernel (fa3_fwd_f32_kernel.h): 16-byte rows, no kernel selector, no split P
+        if (a->flags & (PFA_FLAG_SPLIT_P | PFA_FLAG_VARIANT_MASK)) return PFA_ERR_FLAGS;
+        const int64_t st4[] = {a->q_stride_b, a->q_stride_h, a->q_stride_s, a->k_stride_b, a->k_stride_h, a->k_stride_s,
+                               a->v_stride_b, a->v_stride_h, a->v_stride_s};
+        for (int64_t s : st4)
+            if (s % 4 != 0) return PFA_ERR_STRIDE;
+        if (!a->q || !a->k || !a->v || !a->o) return PFA_ERR_NULL;
+        if (!aligned16(a->q) || !aligned16(a->k) || !aligned16(a->v) || (reinterpret_cast<uintptr_t>(a->o) & 3u)) return PFA_ERR_ALIGN;
+        if (!(a->softmax_scale > 0.f) || !isfinite(a->softmax_scale)) return PFA_ERR_SHAPE;
+        if ((int64_t)((a->Sq + 63) / 64) * a->B * a->H > 0x7fffffffLL) return PFA_ERR_SHAPE;
+        if (a->lse && (reinterpret_cast<uintptr_t>(a->lse) & 3u)) return PFA_ERR_ALIGN;
+        return PFA_OK;
+    }
     if (!(a->softmax_scale > 0.f) || !isfinite(a->softmax_scale)) return PFA_ERR_SHAPE;
     const int64_t st[] = {a->q_stride_b, a->q_stride_h, a->q_stride_s, a->k_stride_b, a->k_stride_h, a->k_stride_s,
                           a->v_stride_b, a->v_stride_h, a->v_stride_s};
@@ -319,13 +333,17 @@ static bool launch_mask_bits(const MaskBits& mb, const pfa_fa3_args* a, void* st
     return hipGetLastError() == hipSuccess;
 }
 
-size_t pfa_fa3_workspace_bytes(const pfa_fa3_args* a) { return a ? mask_bits(a).bytes() : 0; }
+size_t pfa_fa3_workspace_bytes(const pfa_fa3_args* a) { return (a && a->dtype_in != PFA_DTYPE_FP32) ? mask_bits(a).bytes() : 0; }
 
 int pfa_fa3_check(const pfa_fa3_args* a) { return check(a); }
 
 int pfa_fa3_describe(const pfa_fa3_args* a, char* buf, size_t n) {
     const int st = check(a);
     if (st != PFA_OK) return st;
+    if (a->dtype_in == PFA_DTYPE_FP32) {
+        if (buf && n) snprintf(buf, n, "fa3_fwd_f32_d%d_exact", a->D);
+        return ((a->Sq + 63) / 64) * a->B * a->H;
+    }
     const Variant v = pick(a);
     if (buf && n) {
         strncpy(buf, v.name, n - 1);
@@ -336,9 +354,49 @@ int pfa_fa3_describe(const pfa_fa3_args* a, char* buf, size_t n) {
     return nq * a->B * a->H;
 }
 
+static int launch_f32(const pfa_fa3_args* a, void* stream) {
+    pfa::F32Params p;
+    p.q = (const float*)a->q; p.k = (const float*)a->k; p.v = (const float*)a->v; p.o = (float*)a->o;
+    p.lse = a->lse; p.seqlens_k = a->seqlens_k;
+    if (a->mask) {
+        p.mask = a->mask; p.m_sb = a->mask_stride_b; p.m_sh = a->mask_stride_h; p.m_sq = a->mask_stride_q; p.m_sk = a->mask_stride_k;
+    } else {
+        p.mask = a->key_mask; p.m_sb = a->key_mask_stride_b; p.m_sh = 0; p.m_sq = 0; p.m_sk = 1;
+    }
+    p.q_sb = a->q_stride_b; p.q_sh = a->q_stride_h; p.q_ss = a->q_stride_s;
+    p.k_sb = a->k_stride_b; p.k_sh = a->k_stride_h; p.k_ss = a->k_stride_s;
+    p.v_sb = a->v_stride_b; p.v_sh = a->v_stride_h; p.v_ss = a->v_stride_s;
+    p.o_sb = a->o_stride_b; p.o_sh = a->o_stride_h; p.o_ss = a->o_stride_s;
+    p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
+    p.kv_group = a->kv_group > 1 ? a->kv_group : 1;
+    p.causal = a->causal != 0;
+    p.scale = a->softmax_scale;
+    const void* fn = a->D == 128 ? (const void*)&pfa::fa3_fwd_f32_kernel<128> : (const void*)&pfa::fa3_fwd_f32_kernel<64>;
+    const int lds = a->D == 128 ? pfa::f32_lds_bytes<128>() : pfa::f32_lds_bytes<64>();
+    int prev_dev = -1;
+    hipError_t e = hipGetDevice(&prev_dev);
+    if (e == hipSuccess && prev_dev != a->device_id) e = hipSetDevice(a->device_id);
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        (void)hipGetLastError();
+        return PFA_ERR_DEVICE;
+    }
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    void* kargs[] = {&p};
+    e = hipLaunchKernel(fn, dim3((unsigned)(((a->Sq + 63) / 64) * a->B * a->H)), dim3(256), kargs, (size_t)lds, (hipStream_t)stream);
+    if (prev_dev != a->device_id) (void)hipSetDevice(prev_dev);
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        (void)hipGetLastError();
+        return PFA_ERR_LAUNCH;
+    }
+    return PFA_OK;
+}
+
 int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream) {
     const int st = check(a);
     if (st != PFA_OK) return st;
+    if (a->dtype_in == PFA_DTYPE_FP32) return launch_f32(a, stream);
 
     pfa::FwdParams p;
     p.q = a->q; p.k = a->k; p.v = a->v; p.o = a->o;
@@ -416,6 +474,7 @@ int pfa_fa3_weights(const pfa_fa3_args* a, void* w, int32_t w_dtype, int64_t w_s
     if (!probe.o) probe.o = w;
     const int st = check(&probe);
     if (st != PFA_OK) return st;
+    if (a->dtype_in == PFA_DTYPE_FP32) return PFA_ERR_DTYPE;      // the weights pass is MFMA only: hand it the 16-bit operands
     if (!a->lse) return PFA_ERR_NULL;
     if (w_dtype != a->dtype_in && w_dtype != PFA_DTYPE_FP32) return PFA_ERR_DTYPE;
 

@@ -118,10 +118,12 @@ def build_args(q, k, v, out, *, causal=False, seqlens_k=None, key_mask=None, sof
         raise ValueError(f"shape mismatch: q {tuple(q.shape)} k {tuple(k.shape)} v {tuple(v.shape)}")
     if out.shape != (B, H, Sq, D):
         raise ValueError("output shape mismatch")
-    if q.dtype not in (torch.bfloat16, torch.float16) or k.dtype != q.dtype or v.dtype != q.dtype:
-        raise ValueError("q, k, v must share dtype bf16 or fp16")
+    if q.dtype not in (torch.bfloat16, torch.float16, torch.float32) or k.dtype != q.dtype or v.dtype != q.dtype:
+        raise ValueError("q, k, v must share dtype bf16, fp16 or fp32 (fp32: the exact, slow kernel)")
     if out.dtype not in (q.dtype, torch.float32):
         raise ValueError("output dtype must be the input dtype or fp32")
+    if q.dtype == torch.float32 and (split_p or variant):
+        raise ValueError("fp32 operands run the exact fp32 kernel: no split P, no kernel selector")
     if not (q.is_cuda and k.is_cuda and v.is_cuda and out.is_cuda):
         raise ValueError("pfa_fa3_fwd needs device tensors (there is no CPU path)")
     qs, ks, vs, os_ = (_bhsd_strides(t) for t in (q, k, v, out))
@@ -215,7 +217,15 @@ def fa3_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: bo
     if _variant is None:   # tools / tests only: kernel selector (include/pfa_hip.h PFA_FLAG_VARIANT_MASK); never read from the environment
         _variant = 0
     odt = q.dtype if out_dtype is None else out_dtype
-    if split_p is None:
+    if q.dtype == torch.float32:
+        # exact fp32 kernel (csrc/fa3_fwd_f32_kernel.h): every product and sum in fp32, ~two orders of magnitude slower than the
+        # MFMA path; the softmax matrix, if wanted, comes from a 16-bit pass of its own (the weights kernel is MFMA only)
+        if return_weights:
+            raise ValueError("return_weights with fp32 operands: call again with 16-bit operands for the weights")
+        if split_p or _variant:
+            raise ValueError("fp32 operands run the exact fp32 kernel: no split P, no kernel selector")
+        split_p = False
+    elif split_p is None:
         split_p = odt == torch.float32
     if out is None:
         out = torch.empty((B, Sq, H, D), dtype=odt, device=q.device).permute(0, 2, 1, 3)

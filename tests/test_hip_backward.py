@@ -209,13 +209,14 @@ def test_masked_module_trains_and_fp32_module_is_differentiable():
     assert float((out.detach().float().cpu() - ref.detach()).abs().max()) <= 2e-2
     gx = x.grad.float().cpu()
     assert float((gx - xc.grad).abs().max()) <= 0.05 * float(xc.grad.abs().max()) + 1e-6
-    # fp32 module: the forward under autograd is the same parity forward as under no_grad
+    # fp32 module: exact fp32 core under no_grad; under autograd the bf16 forward / backward pair (a warning says so), within its tolerance
     m32 = FlashAttention3(E, H).to(DEV).eval()
     x32 = torch.from_numpy(synth.normal_f32((2, S, E), 32)).to(DEV).requires_grad_(True)
-    y = m32(x32, is_causal=True)[0]
+    with pytest.warns(UserWarning, match="bf16-rounded"):
+        y = m32(x32, is_causal=True)[0]
     with torch.no_grad():
         y0 = m32(x32, is_causal=True)[0]
-    assert y.dtype == torch.float32 and torch.equal(y.detach(), y0)
+    assert y.dtype == torch.float32 and float((y.detach() - y0).abs().max()) <= 3e-2
     y.square().mean().backward()
     assert x32.grad is not None and bool(torch.isfinite(x32.grad).all()) and float(x32.grad.abs().sum()) > 0
     for n_, p_ in m32.named_parameters():

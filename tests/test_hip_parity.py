@@ -249,8 +249,11 @@ def test_bad_arguments_raise_before_launch():
     with pytest.raises(ValueError):
         ops.fa3_forward(q, q, q)                      # head dim 160 (> 128: no kernel; <= 128 runs zero-padded)
     q32 = torch.zeros(1, 2, 16, 64, dtype=torch.float32, device=dev)
+    assert ops.fa3_forward(q32, q32, q32)[0].dtype == torch.float32      # fp32 inputs: the exact fp32 kernel ...
     with pytest.raises(ValueError):
-        ops.fa3_forward(q32, q32, q32)                # fp32 inputs
+        ops.fa3_forward(q32, q32, q32, split_p=True)  # ... which knows no split P / kernel selector / mixed dtypes
+    with pytest.raises(ValueError):
+        ops.fa3_forward(q32, q32.to(torch.bfloat16), q32)
     qc = torch.zeros(1, 2, 16, 64, dtype=torch.bfloat16)
     with pytest.raises(ValueError):
         ops.fa3_forward(qc, qc, qc)                   # host tensors: no CPU path
