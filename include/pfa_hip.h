@@ -66,7 +66,10 @@ typedef enum pfa_dtype {
 /* flags */
 #define PFA_FLAG_SPLIT_P   0x1u  /* carry P as bf16 hi+lo (two PV MFMA passes): the <=1e-3 parity mode        */
 #define PFA_FLAG_NO_XCD_MAP 0x2u /* debugging: identity block->work mapping                                  */
-#define PFA_FLAG_VARIANT_MASK 0xff00u /* development: experimental kernel variant id in bits 8..15 (0 = default) */
+#define PFA_FLAG_VARIANT_MASK 0xff00u /* bits 8..15: kernel selector for tests / A-B runs.  0 = the library chooses; 43 = the 4-wave HIP kernel,
+                                         44 = the 8-wave HIP kernel, 45 = the persistent 4-wave assembly kernel (each only where it applies;
+                                         otherwise the library's choice).  Anything else is PFA_ERR_FLAGS: schedule experiments and
+                                         timing-only ablations exist only in a development build (make DEV=1). */
 
 /*
  * One attention problem: O[b,i,h,:] = softmax_j(scale * <Q[b,i,h,:], K[b,j,h,:]> + mask) V[b,j,h,:]
@@ -157,8 +160,9 @@ int pfa_fa3_weights(const pfa_fa3_args* a, void* w, int32_t w_dtype, int64_t w_s
  * Backward pass (ABI v3).  The reference obtains gradients from autograd through its eager forward
  * (flash_attention_3.py:152-262; its unit tests only require that gradients exist, tests/unit/
  * test_flash_attention_3.py:137-160); this entry point computes dQ, dK, dV from q, k, v, o, dO and the forward's
- * LSE by recomputation (three kernels: delta = rowsum(dO*O), dQ per query block, dK/dV per key block; no atomics,
- * bitwise reproducible).  Masks: `causal` and `seqlens_k` (the general u8 masks are forward-only for now).
+ * LSE by recomputation (two launches: dQ per query block, which also produces delta = rowsum(dO*O), then dK/dV per key block; no
+ * atomics, bitwise reproducible).  Masks: `causal`, `seqlens_k` and the forward's general u8 `mask` (field below; a [B,Sk] key mask
+ * is the broadcast form mask_stride_b = Sk, _h = 0, _q = 0, _k = 1).
  * All tensors [B,S,H,D] by element strides, last dim contiguous; gradients in `dtype_grad` (= dtype or fp32).
  * `delta` is caller-provided scratch of pfa_fa3_bwd_workspace_bytes() bytes ([B,H,Sq] fp32).
  */
