@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define PFA_ABI_VERSION 4
+#define PFA_ABI_VERSION 5
 
 typedef enum pfa_status {
     PFA_OK = 0,
@@ -119,6 +119,14 @@ typedef struct pfa_fa3_args {
      * backward wants expanded K/V (autograd then sums dK/dV over the group). */
     int32_t kv_group;
     int32_t reserved0;          /* must be 0 */
+
+    /* ABI v5: attention dropout of the reference's dense branch (flash_attention_3.py:174-175: dropout(softmax(scores)) @ v).
+     * drop_mask: keep-mask bytes [B][H][Sq][Sk] contiguous (non-zero = keep), drawn by the caller; kept weights are scaled by
+     * drop_scale = 1 / (1 - p), the softmax normaliser is the un-dropped row sum.  Only with dtype_in = fp32 (the fp32 kernels);
+     * NULL = no dropout. */
+    const uint8_t* drop_mask;
+    float   drop_scale;
+    int32_t reserved1;          /* must be 0 */
 } pfa_fa3_args;
 
 /* ABI version of the loaded library (== PFA_ABI_VERSION of the header it was built from). */
@@ -189,7 +197,7 @@ typedef struct pfa_fa3_bwd_args {
     int64_t dk_stride_b, dk_stride_h, dk_stride_s;
     int64_t dv_stride_b, dv_stride_h, dv_stride_s;
     int32_t B, H, Sq, Sk, D;
-    int32_t dtype;              /* PFA_DTYPE_BF16 | PFA_DTYPE_FP16: q,k,v,o,dout */
+    int32_t dtype;              /* PFA_DTYPE_BF16 | PFA_DTYPE_FP16 | PFA_DTYPE_FP32 (v5): q,k,v,o,dout */
     int32_t dtype_grad;         /* = dtype or PFA_DTYPE_FP32: dq,dk,dv */
     int32_t causal;
     float   softmax_scale;
@@ -199,6 +207,11 @@ typedef struct pfa_fa3_bwd_args {
      * gradient; rows the forward found fully masked (lse = -inf) get dq = 0 and contribute nothing to dk, dv. */
     const uint8_t* mask;
     int64_t mask_stride_b, mask_stride_h, mask_stride_q, mask_stride_k;
+    /* ABI v5: dtype = PFA_DTYPE_FP32 (all tensors fp32, strides multiples of 4 elements, `delta` unused) runs the fp32 backward
+     * kernels; only they take the forward's dropout keep-mask (see pfa_fa3_args.drop_mask). */
+    const uint8_t* drop_mask;
+    float   drop_scale;
+    int32_t reserved1;          /* must be 0 */
 } pfa_fa3_bwd_args;
 
 size_t pfa_fa3_bwd_workspace_bytes(const pfa_fa3_bwd_args* a);

@@ -46,13 +46,12 @@ class FlashAttention3(nn.Module):
         """``fp32_attention`` (not in the reference; only matters for fp32 modules, the reference's default dtype): "exact" runs the
         attention core of an fp32 module in fp32 on the vector ALUs -- the reference's numbers to ~1e-6, at a few TFLOP/s -- and is
         the default, so that nothing is rounded behind the caller's back; "bf16" rounds q, k, v to bf16 and takes the MFMA kernels
-        (about 1e-2 from the fp32 reference at the module output, two orders of magnitude faster).  Under autograd the gradients of an
-        fp32 module are always computed by the bf16 forward / backward pair (a warning says so once)."""
+        (about 1e-2 from the fp32 reference at the module output, two orders of magnitude faster).  "exact" covers autograd too: the
+        fp32 forward and the fp32 backward kernels."""
         super().__init__()
         if fp32_attention not in ("exact", "bf16"):
             raise ValueError('fp32_attention must be "exact" or "bf16"')
         self.fp32_attention = fp32_attention
-        self._warned_fp32_grad = False
         self.embed_dim = embed_dim
         self.num_heads = num_heads
         self.dropout = dropout
@@ -142,29 +141,37 @@ class FlashAttention3(nn.Module):
                 "FlashAttention3 runs on MI355X only: move the module and its inputs to a GPU "
                 "(this package ships no CPU or eager implementation of the core)")
         needs_grad = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)
-        if self.training and self.dropout > 0:
-            # The reference applies attention dropout only in its dense branch (:174-175), i.e. when both sequence lengths
-            # fit one tile of min(Sq, Sk, 512) (floor 32, :264-293); its tiled branch (:182-262) has no dropout at all.
-            # Mirror that: longer sequences train with no attention dropout, exactly like the reference; the dense
-            # case has no in-kernel RNG here (it could not match the reference's random stream anyway) and is refused.
-            tile = max(32, min(q.shape[2], k.shape[2], 512))
-            if q.shape[2] <= tile and k.shape[2] <= tile:
-                raise NotImplementedError(
-                    "attention dropout in training mode is not implemented on the HIP path for sequences that fit one "
-                    "tile (<= 512); the reference applies none beyond that either")
         # 2-D [B,Sk] masks take the cheap key-mask path (:166-167); 3-D / 4-D masks the general one (:168,:235)
         key_mask = attention_mask if (attention_mask is not None and attention_mask.dim() == 2) else None
         mask = attention_mask if (attention_mask is not None and attention_mask.dim() != 2) else None
+        if self.training and self.dropout > 0:
+            # The reference applies attention dropout only in its dense branch (:174-175), i.e. when both sequence lengths
+            # fit one tile of min(Sq, Sk, 512) (floor 32, :264-293); its tiled branch (:182-262) has no dropout at all.
+            # Mirror that: longer sequences train with no attention dropout, exactly like the reference; the dense case runs
+            # the fp32 kernels with a keep-mask drawn on the device (torch's generator: the reference's random stream itself
+            # cannot be matched, its statistics are) and replayed by the fp32 backward.
+            tile = max(32, min(q.shape[2], k.shape[2], 512))
+            if q.shape[2] <= tile and k.shape[2] <= tile:
+                if need_weights:
+                    raise NotImplementedError("need_weights together with training-mode attention dropout is not supported")
+                out = ops.fa3_attention_dropout(q, k, v, self.dropout, causal=is_causal, key_mask=key_mask, mask=mask,
+                                                softmax_scale=self.scaling)
+                return out, None
         if needs_grad:
             # differentiable path: HIP forward (with LSE) + HIP backward (pfa_fa3_bwd), masks included.  need_weights (the
             # default of the nn.MultiheadAttention-shaped facade) gets the softmax matrix from the second pass on the saved
             # LSE, DETACHED: the gradient flows through the output only.
+            if q.dtype == torch.float32 and self.fp32_attention == "exact":
+                out = ops.fa3_attention(q, k, v, causal=is_causal, key_mask=key_mask, mask=mask, softmax_scale=self.scaling)   # fp32 kernels, both directions
+                w = None
+                if need_weights:
+                    cd = self.compute_dtype
+                    with torch.no_grad():
+                        w = ops.fa3_forward(q.to(cd), k.to(cd), v.to(cd), causal=is_causal, key_mask=key_mask, mask=mask,
+                                            softmax_scale=self.scaling, out_dtype=torch.float32, weights_dtype=torch.float32,
+                                            return_weights=True)[2]
+                return out, w
             cd = self.compute_dtype if q.dtype == torch.float32 else q.dtype
-            if q.dtype == torch.float32 and self.fp32_attention == "exact" and not self._warned_fp32_grad:
-                import warnings
-                warnings.warn("FlashAttention3: gradients of an fp32 module are computed from bf16-rounded q, k, v (the backward kernels "
-                              "are MFMA only); the forward under torch.no_grad() stays exact fp32", stacklevel=3)
-                self._warned_fp32_grad = True
             res = ops.fa3_attention(q.to(cd), k.to(cd), v.to(cd), causal=is_causal, key_mask=key_mask, mask=mask,
                                     softmax_scale=self.scaling, out_dtype=q.dtype, return_weights=need_weights,
                                     weights_dtype=torch.float32 if q.dtype == torch.float32 else None)

@@ -27,6 +27,10 @@ struct F32Params {
     int64_t m_sb, m_sh, m_sq, m_sk;
     int32_t B, H, Sq, Sk, kv_group, causal;
     float scale;
+    // attention dropout of the reference's dense branch (flash_attention_3.py:174-175: dropout(softmax(scores)) @ v): keep-mask bytes
+    // [B][H][Sq][Sk] contiguous (non-zero = keep), kept weights scaled by drop_scale = 1 / (1 - p); the row sum stays un-dropped
+    const uint8_t* drop_mask;
+    float drop_scale;
 };
 
 template <int D>
@@ -119,7 +123,13 @@ __global__ __launch_bounds__(256) void fa3_fwd_f32_kernel(const F32Params p) {
             for (int j = 0; j < 4; ++j) {
                 const float e = m_new == -INFINITY ? 0.f : __expf(s[i][j] - m_new);
                 rs += e;
-                Ps[(4 * ty + i) * LP + 4 * tx + j] = e;
+                float ed = e;
+                if (p.drop_mask) {
+                    const int kj = k0 + 4 * tx + j;
+                    const bool keep = qi < p.Sq && kj < p.Sk && p.drop_mask[(((int64_t)b * p.H + h) * p.Sq + qi) * p.Sk + kj] != 0;
+                    ed = keep ? e * p.drop_scale : 0.f;
+                }
+                Ps[(4 * ty + i) * LP + 4 * tx + j] = ed;
             }
 #pragma unroll
             for (int w = 1; w < 16; w <<= 1) rs += __shfl_xor(rs, w, 16);

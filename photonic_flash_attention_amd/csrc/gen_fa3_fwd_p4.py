@@ -89,6 +89,7 @@ def PDL(X, i):              # split P: the low halves (the VGPRs the 4-deep frag
     return 176 + (0 if X == 'A' else 16) + i
 
 
+PKADD = int(os.environ.get("P4_PKADD", "0"))        # EXPERIMENT, off: row sums as v_pk_add_f32 on register pairs (32 instead of 64 instructions a tile) ran 5-7 % SLOWER
 RING = int(os.environ.get("P4_RING", "8"))          # K / V^T fragment rings: 4 (VGPRs) or 8 (the spare accumulator registers a[192:255])
 KFR = lambda i: (192 + 4 * (i % 8)) if RING == 8 else (176 + 4 * (i % 4))
 VFR = lambda i: (224 + 4 * (i % 8)) if RING == 8 else (192 + 4 * (i % 4))
@@ -102,6 +103,10 @@ ST = {"m": 0, "l": 1, "mc": 2, "thr": 3, "al": 4, "ps0": 5}
 
 def STV(X, f):
     return 236 + (0 if X == 'A' else 6) + ST[f]
+
+
+def PSP(X):                 # packed row-sum accumulator of a strip (two lanes of a v_pk_add_f32): v[176:177] / v[178:179]
+    return 176 + (0 if X == 'A' else 2)
 
 
 V_PS1 = 248
@@ -212,24 +217,24 @@ class Gen:
         t2 = vr(V_E[14])
         self.i("s_memtime s[58:59]")
         self.i("s_waitcnt lgkmcnt(0)")
-        self.i(f"v_sub_u32 {t2}, s58, v176")
-        self.i(f"v_add_u32 v{177 + k}, v{177 + k}, {t2}")
-        self.i("v_mov_b32 v176, s58")
+        self.i(f"v_sub_u32 {t2}, s58, v184")
+        self.i(f"v_add_u32 v{185 + k}, v{185 + k}, {t2}")
+        self.i("v_mov_b32 v184, s58")
         if count is not None:
-            self.i(f"v_add_u32 v{177 + count}, 1, v{177 + count}")
+            self.i(f"v_add_u32 v{185 + count}, 1, v{185 + count}")
 
     def stamp_init(self):
         if not STAMP:
             return
-        for k in range(177, 193):
+        for k in range(185, 201):
             self.i(f"v_mov_b32 v{k}, 0")
         self.i("s_memtime s[58:59]")
         self.i("s_waitcnt lgkmcnt(0)")
-        self.i("v_mov_b32 v176, s58")
-        self.i("v_mov_b32 v187, s58")                                # bucket 10: cycle counter at kernel start
+        self.i("v_mov_b32 v184, s58")
+        self.i("v_mov_b32 v195, s58")                                # bucket 10: cycle counter at kernel start
         self.i("s_memrealtime s[58:59]")
         self.i("s_waitcnt lgkmcnt(0)")
-        self.i("v_mov_b32 v188, s58")                                # bucket 11: 100 MHz counter at kernel start
+        self.i("v_mov_b32 v196, s58")                                # bucket 11: 100 MHz counter at kernel start
 
     def stamp_dump(self):
         """[workgroup][wave][16] dwords into the dbg buffer (kernarg), by lane 0."""
@@ -241,10 +246,10 @@ class Gen:
         self.i(f"s_cbranch_scc1 {lskip}")
         self.i("s_memtime s[58:59]")
         self.i("s_waitcnt lgkmcnt(0)")
-        self.i("v_sub_u32 v187, s58, v187")                          # total cycles
+        self.i("v_sub_u32 v195, s58, v195")                          # total cycles
         self.i("s_memrealtime s[58:59]")
         self.i("s_waitcnt lgkmcnt(0)")
-        self.i("v_sub_u32 v188, s58, v188")                          # total 10-ns ticks
+        self.i("v_sub_u32 v196, s58, v196")                          # total 10-ns ticks
         self.i(f"s_mov_b32 {S('lsrd', 0)}, {ka('dbg')}")
         self.i(f"s_and_b32 {S('lsrd', 1)}, {ka('dbg', hi=True)}, 0xffff")
         self.i(f"s_mov_b32 {S('lsrd', 2)}, 0x7fffffff")
@@ -254,7 +259,7 @@ class Gen:
         self.i(f"v_mov_b32 {t3}, 0")
         self.i("s_mov_b64 exec, 1")
         for k in range(16):
-            self.i(f"buffer_store_dword v{176 + k}, {t3}, {S('lsrd')}, {S('t0')} offen offset:{4 * k}")
+            self.i(f"buffer_store_dword v{184 + k}, {t3}, {S('lsrd')}, {S('t0')} offen offset:{4 * k}")
         self.i("s_mov_b64 exec, -1")
         self.lab(lskip)
 
@@ -297,6 +302,29 @@ class Gen:
                     r += [f"v_cvt_f32_f16 {t0}, {hi}", f"v_cvt_f32_f16_sdwa {t1}, {hi} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"]
                 r += [f"v_sub_f32 {t0}, {x0}, {t0}", f"v_sub_f32 {t1}, {x1}, {t1}", f"{self.cvt} {vr(PDL(X, i))}, {t0}, {t1}"]
             return r
+        pk = PKADD and not self.split
+        if pk:                                   # sums two at a time: both halves of a register pair per instruction
+            acc = vr(PSP(X), 2)
+            o = [fma(0)]
+            for e in range(16):
+                if e < 15:
+                    o.append(fma(e + 1))
+                o.append(f"v_exp_f32 {c1(e)}, {c1(e)}")
+                if e == 0:
+                    o.append(f"v_pk_add_f32 {acc}, {acc}, {vr(SBUF(buf, X, 0, 14), 2)}")     # left over from the start
+                if e % 2 == 0:
+                    o += pack(e // 2, c0(e), c0(e + 1))
+                elif e >= 3:
+                    o += pack(8 + (e - 3) // 2, c1(e - 3), c1(e - 2))
+                    o.append(f"v_pk_add_f32 {acc}, {acc}, {vr(SBUF(buf, X, 1, e - 3), 2)}")
+            o += pack(15, c1(14), c1(15))
+            o.append(f"v_pk_add_f32 {acc}, {acc}, {vr(SBUF(buf, X, 1, 14), 2)}")
+            o.append("s_nop 0")
+            o.append(f"v_add_f32 {l}, {l}, {vr(PSP(X))}")
+            o.append(f"v_add_f32 {l}, {l}, {vr(PSP(X) + 1)}")
+            o.append(f"v_mov_b32 {vr(PSP(X))}, 0")
+            o.append(f"v_mov_b32 {vr(PSP(X) + 1)}, 0")
+            return o
         o = [fma(0)]
         for e in range(16):
             if e < 15:
@@ -344,7 +372,7 @@ class Gen:
             # branch-free, per row: a max inside the headroom leaves m alone, and then alpha = exp2(0) = 1 exactly
             o += [f"v_cmp_gt_f32 vcc, {mx}, {th}",
                   f"s_or_b64 {S('grow')}, {S('grow')}, vcc",
-                  f"v_mov_b32 {ps0}, 0",
+                  ("s_nop 0" if (PKADD and not self.split) else f"v_mov_b32 {ps0}, 0"),
                   f"v_cndmask_b32 {t0}, {m}, {mx}, vcc",                  # m_new
                   f"v_sub_f32 {t1}, {m}, {t0}",
                   f"v_mul_f32 {t1}, {ka('scale_log2')}, {t1}",
@@ -371,7 +399,10 @@ class Gen:
             if e < 15:
                 o.append(fma(e + 1))
             o.append(f"v_exp_f32 {n0(e)}, {n0(e)}")
-            if e >= 1:
+            if PKADD and not self.split:
+                if e >= 2 and e % 2 == 0:         # the pair (e-2, e-1); the last pair is added by the finish
+                    o.append(f"v_pk_add_f32 {vr(PSP(X), 2)}, {vr(PSP(X), 2)}, {vr(SBUF(buf, X, 0, e - 2), 2)}")
+            elif e >= 1:
                 o.append(f"v_add_f32 {ps0}, {ps0}, {n0(e - 1)}")
         return o
 
@@ -821,6 +852,10 @@ class Gen:
             self.i(f"v_mov_b32 {vr(STV(X, 'ps0'))}, 0")
             self.i(f"v_mov_b32 {vr(STV(X, 'al'))}, 1.0")
         self.i(f"v_mov_b32 {vr(V_PS1)}, 0")
+        if PKADD and not self.split:
+            for X in "AB":
+                self.i(f"v_mov_b32 {vr(PSP(X))}, 0")
+                self.i(f"v_mov_b32 {vr(PSP(X) + 1)}, 0")
         self.i("s_waitcnt lgkmcnt(0)")
         # QK^T(0) from K slot 0 into buffer 0; four O zeros per gap
         zero = [[f"v_accvgpr_write_b32 a{4 * hs + k}, 0" for k in range(4)] for hs in range(32)]

@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include "fa3_bwd_kernels.h"
+#include "fa3_bwd_f32_kernel.h"
 
 namespace {
 
@@ -16,7 +17,22 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 int check_bwd(const pfa_fa3_bwd_args* a) {
     if (!a) return PFA_ERR_NULL;
     if (a->size != sizeof(pfa_fa3_bwd_args)) return PFA_ERR_STRUCT_SIZE;
-    if (a->flags) return PFA_ERR_FLAGS;
+    if (a->flags || a->reserved1) return PFA_ERR_FLAGS;
+    if (a->dtype == PFA_DTYPE_FP32) {          // fp32 backward kernels (fa3_bwd_f32_kernel.h): fp32 everything, the only path with dropout
+        if (!a->q || !a->k || !a->v || !a->o || !a->dout || !a->lse || !a->dq || !a->dk || !a->dv) return PFA_ERR_NULL;
+        if (a->B <= 0 || a->H <= 0 || a->Sq <= 0 || a->Sk <= 0) return PFA_ERR_SHAPE;
+        if (a->D != 64 && a->D != 128) return PFA_ERR_HEAD_DIM;
+        if (a->dtype_grad != PFA_DTYPE_FP32) return PFA_ERR_DTYPE;
+        if (!(a->softmax_scale > 0.f) || !isfinite(a->softmax_scale)) return PFA_ERR_SHAPE;
+        if (a->drop_mask && (!(a->drop_scale >= 1.f) || !isfinite(a->drop_scale))) return PFA_ERR_FLAGS;
+        const int64_t st4[] = {a->q_stride_b, a->q_stride_h, a->q_stride_s, a->k_stride_b, a->k_stride_h, a->k_stride_s,
+                               a->v_stride_b, a->v_stride_h, a->v_stride_s};
+        for (int64_t s : st4)
+            if (s % 4) return PFA_ERR_STRIDE;
+        if (!al16(a->q) || !al16(a->k) || !al16(a->v)) return PFA_ERR_ALIGN;
+        return PFA_OK;
+    }
+    if (a->drop_mask) return PFA_ERR_FLAGS;
     if (!a->q || !a->k || !a->v || !a->o || !a->dout || !a->lse || !a->dq || !a->dk || !a->dv || !a->delta) return PFA_ERR_NULL;
     if (a->B <= 0 || a->H <= 0 || a->Sq <= 0 || a->Sk <= 0) return PFA_ERR_SHAPE;
     if (a->D != 64 && a->D != 128) return PFA_ERR_HEAD_DIM;
@@ -66,6 +82,42 @@ size_t pfa_fa3_bwd_workspace_bytes(const pfa_fa3_bwd_args* a) {
 int pfa_fa3_bwd(const pfa_fa3_bwd_args* a, void* stream) {
     const int st = check_bwd(a);
     if (st != PFA_OK) return st;
+    if (a->dtype == PFA_DTYPE_FP32) {
+        pfa::F32BwdParams p;
+        p.q = (const float*)a->q; p.k = (const float*)a->k; p.v = (const float*)a->v; p.o = (const float*)a->o;
+        p.dout = (const float*)a->dout; p.lse = a->lse;
+        p.dq = (float*)a->dq; p.dk = (float*)a->dk; p.dv = (float*)a->dv;
+        p.seqlens_k = a->seqlens_k; p.mask = a->mask; p.drop_mask = a->drop_mask;
+        p.q_sb = a->q_stride_b; p.q_sh = a->q_stride_h; p.q_ss = a->q_stride_s;
+        p.k_sb = a->k_stride_b; p.k_sh = a->k_stride_h; p.k_ss = a->k_stride_s;
+        p.v_sb = a->v_stride_b; p.v_sh = a->v_stride_h; p.v_ss = a->v_stride_s;
+        p.o_sb = a->o_stride_b; p.o_sh = a->o_stride_h; p.o_ss = a->o_stride_s;
+        p.do_sb = a->do_stride_b; p.do_sh = a->do_stride_h; p.do_ss = a->do_stride_s;
+        p.dq_sb = a->dq_stride_b; p.dq_sh = a->dq_stride_h; p.dq_ss = a->dq_stride_s;
+        p.dk_sb = a->dk_stride_b; p.dk_sh = a->dk_stride_h; p.dk_ss = a->dk_stride_s;
+        p.dv_sb = a->dv_stride_b; p.dv_sh = a->dv_stride_h; p.dv_ss = a->dv_stride_s;
+        p.m_sb = a->mask_stride_b; p.m_sh = a->mask_stride_h; p.m_sq = a->mask_stride_q; p.m_sk = a->mask_stride_k;
+        p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk; p.causal = a->causal != 0;
+        p.scale = a->softmax_scale; p.drop_scale = a->drop_scale;
+        const void* f0 = a->D == 128 ? (const void*)&pfa::fa3_bwd_f32_kernel<128, 0> : (const void*)&pfa::fa3_bwd_f32_kernel<64, 0>;
+        const void* f1 = a->D == 128 ? (const void*)&pfa::fa3_bwd_f32_kernel<128, 1> : (const void*)&pfa::fa3_bwd_f32_kernel<64, 1>;
+        const int lds = a->D == 128 ? pfa::f32_bwd_lds_bytes<128>() : pfa::f32_bwd_lds_bytes<64>();
+        int prev = -1;
+        hipError_t e = hipGetDevice(&prev);
+        if (e == hipSuccess && prev != a->device_id) e = hipSetDevice(a->device_id);
+        if (e != hipSuccess) { (void)hipGetLastError(); return PFA_ERR_DEVICE; }
+        if (lds > 64 * 1024) {
+            (void)hipFuncSetAttribute(f0, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        }
+        void* kargs[] = {&p};
+        e = hipLaunchKernel(f0, dim3((unsigned)(((a->Sq + 63) / 64) * a->B * a->H)), dim3(256), kargs, (size_t)lds, (hipStream_t)stream);
+        if (e == hipSuccess)
+            e = hipLaunchKernel(f1, dim3((unsigned)(((a->Sk + 63) / 64) * a->B * a->H)), dim3(256), kargs, (size_t)lds, (hipStream_t)stream);
+        if (prev != a->device_id) (void)hipSetDevice(prev);
+        if (e != hipSuccess) { (void)hipGetLastError(); return PFA_ERR_LAUNCH; }
+        return PFA_OK;
+    }
     pfa::BwdParams p;
     p.q = a->q; p.k = a->k; p.v = a->v; p.o = a->o; p.dout = a->dout; p.lse = a->lse; p.delta = a->delta;
     p.dq = a->dq; p.dk = a->dk; p.dv = a->dv; p.seqlens_k = a->seqlens_k;

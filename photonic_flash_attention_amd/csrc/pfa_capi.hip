@@ -210,7 +210,8 @@ int check(const pfa_fa3_args* a) {
 #endif
     if (!a->q || !a->k || !a->v || !a->o) return PFA_ERR_NULL;
     if (a->key_mask && a->mask) return PFA_ERR_FLAGS;
-    if (a->kv_group < 0 || a->reserved0 != 0 || (a->kv_group > 1 && a->H % a->kv_group != 0)) return PFA_ERR_SHAPE;
+    if (a->kv_group < 0 || a->reserved0 != 0 || a->reserved1 != 0 || (a->kv_group > 1 && a->H % a->kv_group != 0)) return PFA_ERR_SHAPE;
+    if (a->drop_mask && (a->dtype_in != PFA_DTYPE_FP32 || !(a->drop_scale >= 1.f) || !isfinite(a->drop_scale))) return PFA_ERR_FLAGS;
     if (a->B <= 0 || a->H <= 0 || a->Sq <= 0 || a->Sk <= 0) return PFA_ERR_SHAPE;
     if (a->D != 64 && a->D != 128) return PFA_ERR_HEAD_DIM;
     if (a->dtype_in != PFA_DTYPE_BF16 && a->dtype_in != PFA_DTYPE_FP16 && a->dtype_in != PFA_DTYPE_FP32) return PFA_ERR_DTYPE;
@@ -279,7 +280,7 @@ const char* pfa_status_string(int status) {
         case PFA_ERR_ALIGN: return "q/k/v/o base pointers must be 16-byte aligned";
         case PFA_ERR_DEVICE: return "device is not a supported gfx950 part";
         case PFA_ERR_LAUNCH: return "HIP kernel launch failed";
-        case PFA_ERR_FLAGS: return "unknown flag bits, or both key_mask and mask set";
+        case PFA_ERR_FLAGS: return "unknown flag bits, both key_mask and mask set, or drop_mask without fp32 operands";
         default: return "unknown pfa_status";
     }
 }
@@ -371,6 +372,8 @@ static int launch_f32(const pfa_fa3_args* a, void* stream) {
     p.kv_group = a->kv_group > 1 ? a->kv_group : 1;
     p.causal = a->causal != 0;
     p.scale = a->softmax_scale;
+    p.drop_mask = a->drop_mask;
+    p.drop_scale = a->drop_scale;
     const void* fn = a->D == 128 ? (const void*)&pfa::fa3_fwd_f32_kernel<128> : (const void*)&pfa::fa3_fwd_f32_kernel<64>;
     const int lds = a->D == 128 ? pfa::f32_lds_bytes<128>() : pfa::f32_lds_bytes<64>();
     int prev_dev = -1;

@@ -75,6 +75,16 @@ def _seqlens_tensor(seqlens_k, device) -> torch.Tensor:
     return t
 
 
+def _drop_mask_ptr(drop_mask, B, H, Sq, Sk, like) -> int:
+    """keep-mask of the dense branch's attention dropout: contiguous u8 / bool [B,H,Sq,Sk] on the operands' device, fp32 kernels only"""
+    if like.dtype != torch.float32:
+        raise ValueError("attention dropout runs on the fp32 kernels: hand over fp32 operands")
+    if drop_mask.shape != (B, H, Sq, Sk) or drop_mask.dtype not in (torch.uint8, torch.bool) or not drop_mask.is_contiguous() \
+            or drop_mask.device != like.device:
+        raise ValueError("drop_mask must be a contiguous u8 / bool [B, H, Sq, Sk] tensor on the operands' device")
+    return drop_mask.data_ptr()
+
+
 def _bhsd_strides(t: torch.Tensor):
     sb, sh, ss, sd = t.stride()
     if sd != 1 and t.shape[3] != 1:
@@ -109,7 +119,7 @@ def _as_mask4(mask: torch.Tensor, B: int, H: int, Sq: int, Sk: int, device) -> t
 
 
 def build_args(q, k, v, out, *, causal=False, seqlens_k=None, key_mask=None, softmax_scale=None,
-               lse=None, split_p=False, variant=0, mask=None):
+               lse=None, split_p=False, variant=0, mask=None, drop_mask=None, drop_scale=1.0):
     """Fill a ``pfa_fa3_args`` from ``[B,H,S,D]``-shaped (arbitrarily strided) tensors."""
     B, H, Sq, D = q.shape
     Sk, Hkv = k.shape[2], k.shape[1]
@@ -178,6 +188,9 @@ def build_args(q, k, v, out, *, causal=False, seqlens_k=None, key_mask=None, sof
         if lse.shape != (B, H, Sq) or lse.dtype != torch.float32 or not lse.is_contiguous():
             raise ValueError("lse must be contiguous fp32 [B, H, Sq]")
         a.lse = lse.data_ptr()
+    if drop_mask is not None:
+        a.drop_mask, a.drop_scale = _drop_mask_ptr(drop_mask, B, H, Sq, Sk, q), float(drop_scale)
+        keep.append(drop_mask)
     return a, keep
 
 
@@ -185,7 +198,7 @@ def fa3_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: bo
                 seqlens_k=None, key_mask: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None,
                 softmax_scale: Optional[float] = None, out_dtype: Optional[torch.dtype] = None,
                 return_lse: bool = False, return_weights: bool = False, weights_dtype: Optional[torch.dtype] = None,
-                split_p: Optional[bool] = None,
+                split_p: Optional[bool] = None, drop_mask: Optional[torch.Tensor] = None, drop_scale: float = 1.0,
                 out: Optional[torch.Tensor] = None, _variant: Optional[int] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """softmax(scale * q k^T + mask) v on the MI355X kernel.
 
@@ -208,7 +221,7 @@ def fa3_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: bo
                           key_mask=key_mask, mask=mask,
                           softmax_scale=float(D ** -0.5 if softmax_scale is None else softmax_scale), out_dtype=out_dtype,
                           return_lse=return_lse, return_weights=return_weights, weights_dtype=weights_dtype,
-                          split_p=split_p, _variant=_variant)
+                          split_p=split_p, drop_mask=drop_mask, drop_scale=drop_scale, _variant=_variant)
         o = res[0][..., :D]
         if out is not None:
             out.copy_(o)
@@ -231,7 +244,8 @@ def fa3_forward(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: bo
         out = torch.empty((B, Sq, H, D), dtype=odt, device=q.device).permute(0, 2, 1, 3)
     lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device) if (return_lse or return_weights) else None
     args, keep = build_args(q, k, v, out, causal=causal, seqlens_k=seqlens_k, key_mask=key_mask, mask=mask,
-                            softmax_scale=softmax_scale, lse=lse, split_p=split_p, variant=_variant)
+                            softmax_scale=softmax_scale, lse=lse, split_p=split_p, variant=_variant,
+                            drop_mask=drop_mask, drop_scale=drop_scale)
     stream = torch.cuda.current_stream(q.device).cuda_stream
     st = _capi.load().pfa_fa3_fwd(C.byref(args), C.c_void_p(stream))
     if st in (-3, -4, -5, -6, -7, -10):
@@ -261,7 +275,8 @@ def fa3_forward_bshd(q, k, v, **kw):
 
 
 def fa3_backward(q, k, v, out, dout, lse, *, causal: bool = False, seqlens_k=None, key_mask=None, mask=None,
-                 softmax_scale: Optional[float] = None, grad_dtype: Optional[torch.dtype] = None):
+                 softmax_scale: Optional[float] = None, grad_dtype: Optional[torch.dtype] = None,
+                 drop_mask: Optional[torch.Tensor] = None, drop_scale: float = 1.0):
     """dQ, dK, dV of ``fa3_forward`` (``pfa_fa3_bwd``).  All operands ``[B,H,S,D]``-shaped (any strides, head dim
     contiguous), ``lse`` the forward's ``[B,H,Sq]`` fp32 LSE.  Returns gradients as ``[B,H,S,D]`` views of
     ``[B,S,H,D]`` buffers, in ``grad_dtype`` (input dtype by default, or fp32).  ``key_mask`` / ``mask``: the masks
@@ -276,7 +291,7 @@ def fa3_backward(q, k, v, out, dout, lse, *, causal: bool = False, seqlens_k=Non
         grads = fa3_backward(_pad_d(q, Dp), _pad_d(k, Dp), _pad_d(v, Dp), _pad_d(out, Dp), _pad_d(dout, Dp), lse,
                              causal=causal, seqlens_k=seqlens_k, key_mask=key_mask, mask=mask,
                              softmax_scale=float(D ** -0.5 if softmax_scale is None else softmax_scale),
-                             grad_dtype=grad_dtype)
+                             grad_dtype=grad_dtype, drop_mask=drop_mask, drop_scale=drop_scale)
         return tuple(g[..., :D] for g in grads)
     gdt = q.dtype if grad_dtype is None else grad_dtype
     if dout.stride(3) != 1:
@@ -312,6 +327,9 @@ def fa3_backward(q, k, v, out, dout, lse, *, causal: bool = False, seqlens_k=Non
         st = [0 if m4.shape[i] == 1 else m4.stride(i) for i in range(4)]
         a.mask_stride_b, a.mask_stride_h, a.mask_stride_q, a.mask_stride_k = st[0], st[1], st[2], (st[3] or 1)
         keep.append(m4)
+    if drop_mask is not None:
+        a.drop_mask, a.drop_scale = _drop_mask_ptr(drop_mask, B, H, Sq, Sk, q), float(drop_scale)
+        keep.append(drop_mask)
     a.B, a.H, a.Sq, a.Sk, a.D = B, H, Sq, Sk, D
     a.dtype, a.dtype_grad, a.causal = _DT[q.dtype], _DT[gdt], 1 if causal else 0
     a.softmax_scale = float(D ** -0.5 if softmax_scale is None else softmax_scale)
@@ -337,7 +355,7 @@ class _FA3Function(torch.autograd.Function):
                           softmax_scale=softmax_scale, return_lse=True, out_dtype=out_dtype,
                           return_weights=want_weights, weights_dtype=weights_dtype)
         out, lse = res[0], res[1]
-        o16 = out if out.dtype == q.dtype else out.to(q.dtype)
+        o16 = out if out.dtype == q.dtype else out.to(q.dtype)     # (fp32 operands: the fp32 kernels in both directions, nothing is narrowed)
         ctx.save_for_backward(q, k, v, o16, lse)
         ctx.causal, ctx.seqlens_k, ctx.softmax_scale = causal, seqlens_k, softmax_scale
         ctx.key_mask, ctx.mask = key_mask, mask          # masks carry no gradient
@@ -354,6 +372,42 @@ class _FA3Function(torch.autograd.Function):
         dq, dk, dv = fa3_backward(q, k, v, out, dout.to(q.dtype), lse, causal=ctx.causal, seqlens_k=ctx.seqlens_k,
                                   key_mask=ctx.key_mask, mask=ctx.mask, softmax_scale=ctx.softmax_scale)
         return dq, dk, dv, None, None, None, None, None, None, None, None
+
+
+class _FA3DropoutFunction(torch.autograd.Function):
+    """Attention with dropout on the softmax weights (the reference's dense branch, flash_attention_3.py:174-175), forward and
+    backward on the fp32 kernels.  The keep-mask is drawn on the device with torch's generator (``torch.manual_seed`` governs it,
+    as it governs ``nn.Dropout`` in the reference) and replayed by the backward."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, p_drop, causal, softmax_scale, key_mask, mask):
+        B, H, Sq, _ = q.shape
+        Sk = k.shape[2]
+        keep = torch.rand((B, H, Sq, Sk), device=q.device) >= p_drop
+        scale = 1.0 / (1.0 - p_drop)
+        q32, k32, v32 = q.float(), k.float(), v.float()
+        out, lse = fa3_forward(q32, k32, v32, causal=causal, key_mask=key_mask, mask=mask, softmax_scale=softmax_scale,
+                               return_lse=True, drop_mask=keep, drop_scale=scale)
+        ctx.save_for_backward(q32, k32, v32, out, lse, keep)
+        ctx.meta = (causal, softmax_scale, key_mask, mask, scale, q.dtype)
+        return out.to(q.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse, keep = ctx.saved_tensors
+        causal, softmax_scale, key_mask, mask, scale, dt = ctx.meta
+        dq, dk, dv = fa3_backward(q, k, v, out, dout.float(), lse, causal=causal, key_mask=key_mask, mask=mask,
+                                  softmax_scale=softmax_scale, drop_mask=keep, drop_scale=scale)
+        return dq.to(dt), dk.to(dt), dv.to(dt), None, None, None, None, None
+
+
+def fa3_attention_dropout(q, k, v, p_drop: float, *, causal: bool = False, key_mask=None, mask=None,
+                          softmax_scale: Optional[float] = None):
+    """``dropout(softmax(scale q k^T + mask), p_drop) v`` on ``[B,H,S,D]`` operands of any float dtype, differentiable; fp32 kernels
+    (meant for the short sequences of the reference's dense branch)."""
+    if not 0.0 <= p_drop < 1.0:
+        raise ValueError("dropout probability must be in [0, 1)")
+    return _FA3DropoutFunction.apply(q, k, v, float(p_drop), causal, softmax_scale, key_mask, mask)
 
 
 def fa3_attention(q, k, v, *, causal: bool = False, seqlens_k=None, key_mask=None, mask=None,
