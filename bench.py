@@ -82,8 +82,9 @@ def self_launch(args) -> int:
     rc = procs[0].returncode
     for p in procs[1:]:
         rc = max(rc, p.wait())
-    sys.stdout.write(out)
-    sys.stdout.flush()
+    for ln in out.splitlines():          # rank 0's JSON line only (the gloo rehearsal backend chats on stdout)
+        if ln.startswith("{"):
+            print(ln, flush=True)
     return rc
 
 
