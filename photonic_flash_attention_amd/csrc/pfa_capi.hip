@@ -128,8 +128,10 @@ Variant pick(const pfa_fa3_args* a) {
     const bool w4_ok = a->D == 128 && !split && !kmask && (int64_t)a->B * a->H * a->H < (1ll << 32);   // last: its multiply-high head index
     const int64_t avg_tiles = (causal ? (int64_t)a->Sk / 2 : (int64_t)a->Sk) / pfa::BLOCK_N;
     // Production selectors (A/B and tests): 43 = the 4-wave HIP kernel, 44 = the 8-wave kernel, 45 = the persistent assembly kernel.
-    // The persistent kernel takes the long aligned problems (pfa::p4_eligible), the 4-wave HIP kernel the other long ones.
-    if (pfa::p4_eligible(a) && (var == 45 || (var == 0 && avg_tiles >= 16))) {
+    // The persistent kernel takes every aligned problem (pfa::p4_eligible): without a cold fill per Q block it also wins on short
+    // sequences (same box, against the better HIP kernel: S256 +26 %, S512 +22 %, S512 causal +18 %, S1024 +12 %, S1024 causal
+    // +24 %, S2048 causal +12 %: profiles/r02_p4_experiments.txt); the 4-wave HIP kernel keeps the other long problems.
+    if (pfa::p4_eligible(a) && (var == 45 || var == 0)) {
         Variant v = p4_variant(a, causal);
         if (v.p4_grid > 0) return v;           // (0: the code object did not load on this device -- fall through to the HIP kernels)
     }
