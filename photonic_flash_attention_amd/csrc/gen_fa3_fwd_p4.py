@@ -28,10 +28,8 @@ import sys
 
 # ------------------------------------------------------------------------------------------------------------------------------
 # LDS map (bytes): K ring 2 x 16 KiB, V ring 2 x 16 KiB, Q landing zone 4 waves x 16 KiB, O staging 4 waves x 8 KiB = 160 KiB
-TILE = 16384
-K_BASE, V_BASE, Q_BASE, O_BASE = 0, 2 * TILE, 4 * TILE, 8 * TILE
-LDS_BYTES = 8 * TILE + 4 * 8192
-HALF = TILE // 2
+# per kernel (Gen.__init__): TILE = 64 keys x D x 2 B (16 KiB at D = 128, 8 KiB at D = 64); K ring at 0, V ring at 2 TILE, the waves'
+# Q landing zones (64 rows each = TILE) at 4 TILE, their O staging (32 rows = TILE / 2) at 8 TILE: 10 TILE in all
 
 # kernarg dwords (struct pfa::P4Params in pfa_p4.hip -- static_asserted there against these offsets)
 KA = dict(q=0, k=2, v=4, o=6, lse=8, q_sb=10, q_sh=11, k_sb=12, k_sh=13, v_sb=14, v_sh=15, o_sb=16, o_sh=17,
@@ -94,7 +92,7 @@ RING = int(os.environ.get("P4_RING", "8"))          # K / V^T fragment rings: 4 
 KFR = lambda i: (192 + 4 * (i % 8)) if RING == 8 else (176 + 4 * (i % 4))
 VFR = lambda i: (224 + 4 * (i % 8)) if RING == 8 else (192 + 4 * (i % 4))
 KOFF = lambda ks: 208 + ks
-VOFF = lambda db, hi: 216 + 2 * db + hi
+VOFF = lambda sel, hi: 216 + 2 * sel + hi       # sel: d block (D = 128) / 2 * (k-step parity) + d block (D = 64)
 KDOFF = lambda t: 224 + t
 VDOFF = lambda t: 228 + t
 QDOFF = lambda t: 232 + t
@@ -115,8 +113,6 @@ V_T = [250, 251, 252, 253]
 V_TA = 254            # causal: r + 1 - 4h (element-mask threshold of the diagonal tile, see mask_diag)
 V_LANE = 255
 V_E = list(range(0, 16))   # prologue / epilogue / rescale scratch (v0 = workitem id at entry)
-OA = lambda X, db, e=0: (0 if X == 'A' else 64) + 16 * db + e
-QA = lambda X, ks: 128 + (0 if X == 'A' else 32) + 4 * ks
 import os
 STAMP = int(os.environ.get("P4_STAMP", "0"))      # 1: every phase; 2: one stamp per iteration only (buckets 0 / 1 stay empty)
 ABL = os.environ.get("P4_ABL", "")                                         # timing-only ablations, see dma_plan
@@ -159,18 +155,34 @@ class Lgkm:
 
 
 class Gen:
-    def __init__(self, dtype, causal, out32=False, split=False):
+    def __init__(self, dtype, causal, out32=False, split=False, D=128):
         """out32: fp32 store (straight from the accumulators); split: P enters the PV product as a 16-bit hi + lo pair (two MFMAs per
         fragment, P's rounding error 2^-18 instead of 2^-9): together the <= 1e-3 parity variant on the benched schedule."""
         assert out32 == split, "the code object carries the fast variant (16-bit store, one P) and the parity variant (fp32 store, split P)"
         self.dt, self.causal, self.out32, self.split = dtype, causal, out32, split
+        assert D in (64, 128)
+        self.D, self.KS, self.DB = D, D // 16, D // 32                 # head dim, k-steps of QK^T, 32-wide d blocks of PV
+        self.NKF, self.NVF = 2 * self.KS, 4 * self.DB                   # K / V^T fragments per 64-key tile
+        self.TILE = 128 * D
+        self.HALF = self.TILE // 2
+        self.K_BASE, self.V_BASE, self.Q_BASE, self.O_BASE = 0, 2 * self.TILE, 4 * self.TILE, 8 * self.TILE
+        self.LDS_BYTES = 10 * self.TILE
+        self.PPW = self.TILE // 4096                                    # 1-KiB DMA pieces per wave and image
+        self.RB, self.CPR = 2 * D, D // 8                               # bytes and 16-byte chunks of a Q / O row
+        self.RING = min(RING, self.NKF)
         self.mf = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
-        self.name = f"fa3_fwd_p4_{dtype}_{'causal' if causal else 'full'}_{'splitp_o32' if out32 else 'o16'}"
+        self.name = f"fa3_fwd_p4_{dtype}_d{D}_{'causal' if causal else 'full'}_{'splitp_o32' if out32 else 'o16'}"
         self.main, self.ool = [], []
         self.L = self.main
         self.abl_on = False
         self.uid = 0
+
+    def OA(self, X, db, e=0):                  # accumulator register of O, strip X, d block db, element e
+        return (0 if X == 'A' else 16 * self.DB) + 16 * db + e
+
+    def QA(self, X, ks):                       # accumulator registers of the Q fragment of k-step ks
+        return 32 * self.DB + (0 if X == 'A' else 4 * self.KS) + 4 * ks
 
     # ---- emission helpers ------------------------------------------------------------------------------------------------
     def i(self, s):
@@ -265,22 +277,25 @@ class Gen:
 
     # ---- building blocks -------------------------------------------------------------------------------------------------
     def kread(self, slot, i):                 # K fragment i = (kb, ks) of the K tile in ring slot `slot` -> ring register i % 4
-        kb, ks = i // 8, i % 8
-        return f"ds_read_b128 {fr(KFR(i), 4)}, {vr(KOFF(ks))} offset:{K_BASE + slot * TILE + kb * HALF}"
+        kb, ks = i // self.KS, i % self.KS
+        return f"ds_read_b128 {fr(KFR(i), 4)}, {vr(KOFF(ks))} offset:{self.K_BASE + slot * self.TILE + kb * self.HALF}"
 
     def vread(self, slot, idx):               # V^T fragment idx = (f, db): two transposed 8-byte reads (rows +0 / +8)
-        f, db = idx // 4, idx % 4
-        ko = slot * TILE + (f // 2) * HALF + (f & 1) * 16 * 256
+        f, db = idx // self.DB, idx % self.DB              # k-step f = (key block, 16-key half), d block db
+        if self.D == 128:                                  # one key per LDS row: the 16-key half is an offset
+            ko, sel = slot * self.TILE + (f // 2) * self.HALF + (f & 1) * 16 * 256, db
+        else:                                              # two keys per LDS row: the half enters the swizzle, so it has its own address registers
+            ko, sel = slot * self.TILE + (f // 2) * self.HALF, 2 * (f & 1) + db
         b = VFR(idx)
-        return [f"ds_read_b64_tr_b16 {fr(b, 2)}, {vr(VOFF(db, 0))} offset:{ko}",
-                f"ds_read_b64_tr_b16 {fr(b + 2, 2)}, {vr(VOFF(db, 1))} offset:{ko}"]
+        return [f"ds_read_b64_tr_b16 {fr(b, 2)}, {vr(VOFF(sel, 0))} offset:{ko}",
+                f"ds_read_b64_tr_b16 {fr(b + 2, 2)}, {vr(VOFF(sel, 1))} offset:{ko}"]
 
     def dma(self, which, t):                  # piece t of this wave's four (M0 already points at the wave's 4 KiB of the slot)
         off, srd, so = (KDOFF(t), S("ksrd"), S("koff")) if which == 'K' else (VDOFF(t), S("vsrd"), S("voff"))
         return f"buffer_load_dwordx4 {vr(off)}, {srd}, {so} offen offset:{1024 * t} lds"
 
     def setm0(self, which, slot):             # M0 = this wave's 4 KiB of ring slot `slot` of the K / V ring  (clobbers SCC)
-        return f"s_add_u32 m0, {S('w4k')}, {(K_BASE if which == 'k' else V_BASE) + slot * TILE}"
+        return f"s_add_u32 m0, {S('w4k')}, {(self.K_BASE if which == 'k' else self.V_BASE) + slot * self.TILE}"
 
     # softmax FINISH of strip X on buffer `buf`: the exponentials of key block 1 and all sixteen P dwords, as an in-order stream.
     # The v_fma of element e+1 is issued ahead of the v_exp of element e and no two dependent adds are adjacent (a dependent VALU
@@ -407,58 +422,65 @@ class Gen:
         return o
 
     def qk_mfma(self, buf, X, i):
-        kb, ks = i // 8, i % 8
+        kb, ks = i // self.KS, i % self.KS
         acc = vr(SBUF(buf, X, kb, 0), 16)
-        return f"{self.mf} {acc}, {fr(KFR(i), 4)}, {ar(QA(X, ks), 4)}, {'0' if ks == 0 else acc}"
+        return f"{self.mf} {acc}, {fr(KFR(i), 4)}, {ar(self.QA(X, ks), 4)}, {'0' if ks == 0 else acc}"
 
     def pv_mfma(self, X, idx, lo=False):
-        f, db = idx // 4, idx % 4
-        acc = ar(OA(X, db), 16)
+        f, db = idx // self.DB, idx % self.DB
+        acc = ar(self.OA(X, db), 16)
         return f"{self.mf} {acc}, {fr(VFR(idx), 4)}, {vr((PDL if lo else PD)(X, 4 * f), 4)}, {acc}"
 
     # ---- phases ----------------------------------------------------------------------------------------------------------
-    def phase_qk(self, p, fillers, dma_at, lg=None, pre=(), tail_vreads=None):
-        """QK^T(j+1) into buffer 1-p from K slot 1-p; fillers[hs] = instructions for the gap behind MFMA hs.  tail_vreads = V slot
-        whose first four V^T fragments are requested in the last gaps (after the last K read), for the PV phase that follows."""
-        nb, slot = 1 - p, 1 - p
+    def phase_qk(self, p, fillers, dma_at, lg=None, pre=(), tail_vreads=None, rec=None):
+        """QK^T(j+1) into buffer 1-p from K slot 1-p; fillers[g] = instructions for the gap behind MFMA g (a fragment feeds strip A,
+        then strip B).  tail_vreads = V slot whose first RING V^T fragments are requested in the last gaps (after the last K read),
+        for the PV phase that follows.  rec (dry run): gets the issue cycles of every gap's fixed content instead of fillers."""
+        nb, slot, R, NF = 1 - p, 1 - p, self.RING, self.NKF
+        ngaps = 2 * NF
         lg = lg or Lgkm()
-        for i in range(RING):
+        for i in range(R):
             self.i(self.kread(slot, i))
             lg.issue(('k', i))
         self.emit(pre)
-        for hs in range(32):
+        for hs in range(ngaps):
             i, X = hs // 2, 'AB'[hs % 2]
+            mark = len(self.L)
             if hs % 2 == 0 and i % 2 == 0:
                 w = lg.need([('k', i), ('k', i + 1)])
                 if w:
                     self.i(w)
             self.i(self.qk_mfma(nb, X, i))
             if hs % 2 == 1 and i % 2 == 1:
-                for f in (i + RING - 1, i + RING):
-                    if f < 16:
+                for f in (i + R - 1, i + R):
+                    if f < NF:
                         self.i(self.kread(slot, f))
                         lg.issue(('k', f))
-            if tail_vreads is not None and hs >= 32 - RING:
-                for k, x in enumerate(self.vread(tail_vreads, hs - (32 - RING))):
+            if tail_vreads is not None and hs >= ngaps - min(R, self.NVF):
+                n = hs - (ngaps - min(R, self.NVF))
+                for k, x in enumerate(self.vread(tail_vreads, n)):
                     self.i(x)
-                    lg.issue(('v', hs - (32 - RING), k))
+                    lg.issue(('v', n, k))
             self.emit(dma_at.get(hs, []))
-            self.emit(fillers[hs])
+            if rec is not None:
+                rec.append(sum(self.price(x.strip()) for x in self.L[mark:] if not x.strip().startswith("v_mfma")))
+            else:
+                self.emit(fillers[hs])
         return lg
 
     def phase_pv(self, p, fillers, dma_at, strips="AB", lg=None, preissued=False, rec=None):
         """PV(j): P dwords x V slot p -> O; one gap per MFMA (split P: a fragment feeds the hi pass of every strip, then the lo pass);
         fillers as above.  rec (dry run): gets the issue cycles of every gap's fixed content instead of emitting fillers."""
-        slot = p
+        slot, R, NF = p, min(self.RING, self.NVF), self.NVF
         lg = lg or Lgkm()
         if not preissued:
-            for idx in range(RING):
+            for idx in range(R):
                 for k, x in enumerate(self.vread(slot, idx)):
                     self.i(x)
                     lg.issue(('v', idx, k))
         hs = 0
         passes = [(X, lo) for lo in ((False, True) if self.split else (False,)) for X in strips]
-        for idx in range(16):
+        for idx in range(NF):
             for n, (X, lo) in enumerate(passes):
                 mark = len(self.L)
                 if n == 0 and idx % 2 == 0:
@@ -467,8 +489,8 @@ class Gen:
                         self.i(w)
                 self.i(self.pv_mfma(X, idx, lo))
                 if n == len(passes) - 1 and idx % 2 == 1:
-                    for f in (idx + RING - 1, idx + RING):
-                        if f < 16:
+                    for f in (idx + R - 1, idx + R):
+                        if f < NF:
                             for k, x in enumerate(self.vread(slot, f)):
                                 self.i(x)
                                 lg.issue(('v', f, k))
@@ -532,13 +554,13 @@ class Gen:
         self.out_of_line(False)
 
     def q_group(self):
-        """Four 1-KiB pieces (16 whole rows) of this wave's share of the NEXT item's Q block -> its landing zone."""
+        """Four 1-KiB pieces (whole rows: 16 at D = 128, 32 at D = 64) of this wave's share of the NEXT item's Q block -> its landing zone."""
         self.i(f"s_mov_b32 m0, {S('qdst')}")
         self.i(f"s_sub_u32 {S('qrem')}, {S('qrem')}, 1")
         for t in range(4):
             self.i(f"buffer_load_dwordx4 {vr(QDOFF(t))}, {S('qsrd_n')}, {S('qoff')} offen offset:{1024 * t} lds")
         self.i(f"s_add_u32 {S('qdst')}, {S('qdst')}, 4096")
-        self.i(f"s_lshl_b32 {S('t0')}, {ka('q_ss')}, 4")
+        self.i(f"s_lshl_b32 {S('t0')}, {ka('q_ss')}, {4 if self.D == 128 else 5}")
         self.i(f"s_add_u32 {S('qoff')}, {S('qoff')}, {S('t0')}")
 
     # ---- bodies ----------------------------------------------------------------------------------------------------------
@@ -606,25 +628,15 @@ class Gen:
         self.abl_on = True
         # ---- phase A: the finish of both strips as ONE in-order stream, sliced evenly over the gaps around their fixed content
         fin = self.finish_stream('A', p) + self.finish_stream('B', p)
-        dma = self.dma_plan(p, DMA_GAPS_V, DMA_GAPS_K)
-        fixed = []
-        for hs in range(32):
-            i = hs // 2
-            f = sum(self.price(x) for x in dma.get(hs, []))
-            if hs % 2 == 1 and i % 2 == 1 and i + RING - 1 < 16:
-                f += 2 * self.price("ds_read")                   # two K fragment reads
-            if hs % 2 == 1 and i % 2 == 1 and i + 1 < 16:
-                f += 4                                           # the s_waitcnt in front of the next MFMA pair
-            if hs >= 32 - RING:
-                f += 2 * self.price("ds_read")                   # V^T fragments for the PV phase
-            fixed.append(f)
+        n = 2 * self.NKF                       # gaps of the QK^T phase; the wave's PPW pieces of V early, of K late
+        gv = [g * n // 32 for g in DMA_GAPS_V][:self.PPW] if self.PPW == 4 else [1 * n // 16, 5 * n // 16]
+        gk = [g * n // 32 for g in DMA_GAPS_K][:self.PPW] if self.PPW == 4 else [9 * n // 16, 13 * n // 16]
+        dma = self.dma_plan(p, gv, gk)
         npre = 0
         while sum(self.price(x) for x in fin[:npre + 1]) <= 24:
             npre += 1
         pre, fin = fin[:npre], fin[npre:]
-        fa, tail = self.pack(fin, fixed)
-        lg = self.phase_qk(p, fa, dma, pre=pre, tail_vreads=p)
-        self.emit(tail)
+        lg = self.run_phase(self.phase_qk, fin, Lgkm(), p=p, dma_at=dma, pre=pre, tail_vreads=p)
         self.stamp(0, fine=True)
         if self.causal:                        # the diagonal tile of this wave is tile wnt-1 = j+1  <=>  wrem == 1
             lm, lr = self.ul("mask"), self.ul("masked")
@@ -655,12 +667,12 @@ class Gen:
     def body_last(self, p):
         self.cm(f"LAST body, parity {p}: this wave's last tile -- finish(j), PV(j); nothing to prefetch for the wave itself")
         self.stamp(2)
-        d = self.dma_plan(p, [0, 2, 4, 6], [8, 10, 12, 14])
+        d = self.dma_plan(p, [2 * t for t in range(self.PPW)], [2 * self.PPW + 2 * t for t in range(self.PPW)])    # PV(A) has >= NVF gaps
         self.emit(self.finish_stream('A', p))
         self.i("s_nop 1")
         self.run_phase(self.phase_pv, self.finish_stream('B', p), Lgkm(), p=p, dma_at=d, strips="A")
         self.i("s_nop 1")
-        self.phase_pv(p, [[] for _ in range(32)], {}, strips="B")
+        self.phase_pv(p, [[] for _ in range(2 * self.NVF)], {}, strips="B")
         self.stamp(5)
 
     def body_skip(self, p):
@@ -668,11 +680,11 @@ class Gen:
         self.stamp(2)
         self.i(self.setm0('v', 1 - p))
         self.i("s_nop 0")
-        for t in range(4):
+        for t in range(self.PPW):
             self.i(self.dma('V', t))
         self.i(self.setm0('k', p))
         self.i("s_nop 0")
-        for t in range(4):
+        for t in range(self.PPW):
             self.i(self.dma('K', t))
         self.stamp(6)
 
@@ -699,8 +711,8 @@ class Gen:
         self.i("s_nop 15")                    # last PV MFMA -> v_accvgpr_read
         for X in "AB":
             al = vr(STV(X, 'al'))
-            for b0 in range(0, 64, 4):
-                regs = [OA(X, 0) + b0 + k for k in range(4)]
+            for b0 in range(0, 16 * self.DB, 4):
+                regs = [self.OA(X, 0) + b0 + k for k in range(4)]
                 for k, a in enumerate(regs):
                     self.i(f"v_accvgpr_read_b32 {vr(V_E[k])}, a{a}")
                 for k in range(4):
@@ -826,24 +838,28 @@ class Gen:
         """Q fragments out of the landing zone into the accumulator file, state, QK^T(0) (O zeroed in its shadow), softmax start(0)."""
         self.cm("item prologue")
         # this item's Q pieces: everything but the previous item's output stores (issued after them: 16, or 32 of the fp32 epilogue)
-        self.i(f"s_waitcnt vmcnt({32 if self.out32 else 16})")
+        self.i(f"s_waitcnt vmcnt({(8 if self.out32 else 4) * self.DB})")
         qb = V_E[0:8]        # per-lane addresses of the Q fragments (recomputed per item: nothing lane-constant is kept live for it)
         T0, T1, T2 = (vr(x) for x in V_T[0:3])
         # address = qland + r * 256 + (((2 ks + h) ^ (r & 15)) << 4)  =  rowbase ^ (32 ks),  qland = Q_BASE + wave * 16384
         self.i(f"s_lshl_b32 {S('t0')}, {S('w4k')}, 2")
-        self.i(f"s_add_u32 {S('t0')}, {S('t0')}, {Q_BASE}")
-        self.i(f"v_and_b32 {T0}, 31, {vr(V_LANE)}")                               # r
-        self.i(f"v_lshrrev_b32 {T1}, 5, {vr(V_LANE)}")                            # h
-        self.i(f"v_and_b32 {T2}, 15, {T0}")
-        self.i(f"v_xor_b32 {T2}, {T2}, {T1}")
-        self.i(f"v_lshlrev_b32 {T2}, 4, {T2}")
-        self.i(f"v_lshl_add_u32 {T2}, {T0}, 8, {T2}")
-        self.i(f"v_add_u32 {T2}, {S('t0')}, {T2}")
-        for ks in range(8):
-            self.i(f"v_xor_b32 {vr(qb[ks])}, {32 * ks}, {T2}")
-        for X, off in (('A', 0), ('B', 8192)):
+        self.i(f"s_add_u32 {S('t0')}, {S('t0')}, {self.Q_BASE}")
+        if self.D == 128:
+            self.i(f"v_and_b32 {T0}, 31, {vr(V_LANE)}")                               # r
+            self.i(f"v_lshrrev_b32 {T1}, 5, {vr(V_LANE)}")                            # h
+            self.i(f"v_and_b32 {T2}, 15, {T0}")
+            self.i(f"v_xor_b32 {T2}, {T2}, {T1}")
+            self.i(f"v_lshlrev_b32 {T2}, 4, {T2}")
+            self.i(f"v_lshl_add_u32 {T2}, {T0}, 8, {T2}")
+            self.i(f"v_add_u32 {T2}, {S('t0')}, {T2}")
             for ks in range(8):
-                self.i(f"ds_read_b128 {ar(QA(X, ks), 4)}, {vr(qb[ks])} offset:{off}")
+                self.i(f"v_xor_b32 {vr(qb[ks])}, {32 * ks}, {T2}")
+        else:                                  # D = 64: a strip's 32 rows lie in the landing zone exactly as 32 keys lie in a K tile image
+            for ks in range(self.KS):
+                self.i(f"v_add_u32 {vr(qb[ks])}, {S('t0')}, {vr(KOFF(ks))}")
+        for X, off in (('A', 0), ('B', self.HALF)):
+            for ks in range(self.KS):
+                self.i(f"ds_read_b128 {ar(self.QA(X, ks), 4)}, {vr(qb[ks])} offset:{off}")
         for X in "AB":
             self.i(f"v_mov_b32 {vr(STV(X, 'm'))}, {NEG_BIG}")
             self.i(f"v_mov_b32 {vr(STV(X, 'thr'))}, {NEG_BIG}")
@@ -858,7 +874,7 @@ class Gen:
                 self.i(f"v_mov_b32 {vr(PSP(X) + 1)}, 0")
         self.i("s_waitcnt lgkmcnt(0)")
         # QK^T(0) from K slot 0 into buffer 0; four O zeros per gap
-        zero = [[f"v_accvgpr_write_b32 a{4 * hs + k}, 0" for k in range(4)] for hs in range(32)]
+        zero = [[f"v_accvgpr_write_b32 a{4 * hs + k}, 0" for k in range(4)] for hs in range(2 * self.NKF)]
         self.phase_qk(1, zero, {})            # parity argument 1: target buffer 0, K slot 0
         if self.causal:
             lm, lr = self.ul("mask0"), self.ul("masked0")
@@ -889,35 +905,57 @@ class Gen:
         inv, lt, t = V_E[13], V_E[14], V_E[15]
         L, T0, T1, T2, T3 = vr(V_LANE), *(vr(x) for x in V_T)
         gofs = V_PS1
+        W = S('wave')
         self.i(f"s_lshl_b32 {S('t0')}, {S('w4k')}, 1")
-        self.i(f"s_add_u32 {S('t0')}, {S('t0')}, {O_BASE}")                       # ostage = O_BASE + wave * 8192
-        # write base: ostage + r * 256 + ((h ^ (r & 15)) << 4)   (chunk 4 db + g + h lands at ((4 db + g) << 4) ^ that)
+        self.i(f"s_add_u32 {S('t0')}, {S('t0')}, {self.O_BASE}")                  # ostage = O_BASE + wave * TILE / 2
         self.i(f"v_and_b32 {T0}, 31, {L}")
         self.i(f"v_lshrrev_b32 {T1}, 5, {L}")
-        self.i(f"v_and_b32 {T2}, 15, {T0}")
-        self.i(f"v_xor_b32 {T2}, {T2}, {T1}")
-        self.i(f"v_lshlrev_b32 {T2}, 4, {T2}")
-        self.i(f"v_lshl_add_u32 {T2}, {T0}, 8, {T2}")
-        self.i(f"v_add_u32 {vr(vb)}, {S('t0')}, {T2}")
+        if self.D == 128:
+            # write base: ostage + r * 256 + ((h ^ (r & 15)) << 4)   (chunk 4 db + g + h lands at ((4 db + g) << 4) ^ that)
+            self.i(f"v_and_b32 {T2}, 15, {T0}")
+            self.i(f"v_xor_b32 {T2}, {T2}, {T1}")
+            self.i(f"v_lshlrev_b32 {T2}, 4, {T2}")
+            self.i(f"v_lshl_add_u32 {T2}, {T0}, 8, {T2}")
+            self.i(f"v_add_u32 {vr(vb)}, {S('t0')}, {T2}")
+        else:
+            # D = 64: the strip is staged as 32 keys lie in a K tile image (two rows per 256 B, same swizzle): chunk 4 db + g + h of row r
+            # sits where K fragment k-step 2 db + g / 2 is read from
+            self.i(f"v_add_u32 {vr(vb)}, {S('t0')}, {vr(KOFF(0))}")
         # LSE offset of the lane's row inside the item: (64 wave + r) * 4
-        self.i(f"s_lshr_b32 {S('t1')}, {S('w4k')}, 4")
+        self.i(f"s_lshl_b32 {S('t1')}, {W}, 8")
         self.i(f"v_lshlrev_b32 {T3}, 2, {T0}")
         self.i(f"v_add_u32 {T3}, {S('t1')}, {T3}")
-        # read-back bases: ostage + (4 k + q4) * 256 + ((c16 ^ (4 k + q4)) << 4), k = 0..3; rows 16 further: + 4096
-        self.i(f"v_lshrrev_b32 {T0}, 4, {L}")                                   # q4
-        self.i(f"v_and_b32 {T1}, 15, {L}")                                      # c16
-        for k in range(4):
-            self.i(f"v_add_u32 {T2}, {4 * k}, {T0}")                              # row
-            self.i(f"v_xor_b32 {vr(rb[k])}, {T1}, {T2}")
-            self.i(f"v_lshlrev_b32 {vr(rb[k])}, 4, {vr(rb[k])}")
-            self.i(f"v_lshl_add_u32 {vr(rb[k])}, {T2}, 8, {vr(rb[k])}")
-            self.i(f"v_add_u32 {vr(rb[k])}, {S('t0')}, {vr(rb[k])}")
-        # store offset inside the item's output rows: (64 wave + q4) * o_ss + 16 c16
-        self.i(f"s_lshr_b32 {S('t1')}, {S('w4k')}, 6")                             # 64 wave
+        if self.D == 128:
+            # read-back bases: ostage + (4 k + q4) * 256 + ((c16 ^ (4 k + q4)) << 4), k = 0..3; rows 16 further: + 4096
+            self.i(f"v_lshrrev_b32 {T0}, 4, {L}")                                   # q4
+            self.i(f"v_and_b32 {T1}, 15, {L}")                                      # c16
+            for k in range(4):
+                self.i(f"v_add_u32 {T2}, {4 * k}, {T0}")                              # row
+                self.i(f"v_xor_b32 {vr(rb[k])}, {T1}, {T2}")
+                self.i(f"v_lshlrev_b32 {vr(rb[k])}, 4, {vr(rb[k])}")
+                self.i(f"v_lshl_add_u32 {vr(rb[k])}, {T2}, 8, {vr(rb[k])}")
+                self.i(f"v_add_u32 {vr(rb[k])}, {S('t0')}, {vr(rb[k])}")
+        else:
+            # read-back: lane (q8 = lane >> 3, c8 = lane & 7) takes chunk c8 of row 8 k + q8, k = 0..3: LDS row R = 4 k + (q8 >> 1),
+            # position (((q8 & 1) << 3) | c8) ^ sw(R), sw(R) = ((q8 >> 1) << 2) | k
+            self.i(f"v_lshrrev_b32 {T0}, 3, {L}")                                   # q8
+            self.i(f"v_and_b32 {T1}, 15, {L}")                                      # ((q8 & 1) << 3) | c8
+            self.i(f"v_lshrrev_b32 {T2}, 4, {L}")                                   # q8 >> 1
+            for k in range(4):
+                self.i(f"v_lshl_or_b32 {vr(rb[k])}, {T2}, 2, {k}")                    # sw
+                self.i(f"v_xor_b32 {vr(rb[k])}, {vr(rb[k])}, {T1}")
+                self.i(f"v_lshlrev_b32 {vr(rb[k])}, 4, {vr(rb[k])}")
+                self.i(f"v_add_u32 {vr(t)}, {4 * k}, {T2}")                           # R
+                self.i(f"v_lshl_add_u32 {vr(rb[k])}, {vr(t)}, 8, {vr(rb[k])}")
+                self.i(f"v_add_u32 {vr(rb[k])}, {S('t0')}, {vr(rb[k])}")
+            self.i(f"v_and_b32 {T1}, 7, {L}")                                       # c8
+        # store offset inside the item's output rows: (64 wave + q) * o_ss + 16 c
+        self.i(f"s_lshl_b32 {S('t1')}, {W}, 6")                                    # 64 wave
         self.i(f"v_add_u32 {T0}, {S('t1')}, {T0}")
         self.i(f"v_mul_lo_u32 {vr(gofs)}, {T0}, {ka('o_ss')}")
         self.i(f"v_lshl_add_u32 {vr(gofs)}, {T1}, 4, {vr(gofs)}")
-        self.i(f"s_lshl_b32 {S('t1')}, {ka('o_ss')}, 2")                           # four rows
+        RPI = 1024 // self.RB                                                     # rows one store instruction covers
+        self.i(f"s_lshl_b32 {S('t1')}, {ka('o_ss')}, {2 if RPI == 4 else 3}")
         for X in "AB":
             l, mc = vr(STV(X, 'l')), vr(STV(X, 'mc'))
             self.i(f"v_mov_b32 {vr(t)}, {l}")
@@ -929,10 +967,10 @@ class Gen:
             self.i("s_nop 1")
             self.i(f"v_cndmask_b32 {vr(inv)}, 0, {vr(inv)}, vcc")
             w = V_E[0:8]
-            for db in range(4):
+            for db in range(self.DB):
                 for g in (0, 2):
                     for k in range(8):
-                        self.i(f"v_accvgpr_read_b32 {vr(w[k])}, a{OA(X, db, 4 * g + k)}")
+                        self.i(f"v_accvgpr_read_b32 {vr(w[k])}, a{self.OA(X, db, 4 * g + k)}")
                     for k in range(8):
                         self.i(f"v_mul_f32 {vr(w[k])}, {vr(w[k])}, {vr(inv)}")
                     # ua = (w0 w1 | w2 w3), ub = (w4 w5 | w6 w7) -> registers w0 w1 (ua) and w2 w3 (ub) after conversion
@@ -959,17 +997,18 @@ class Gen:
             self.i("s_mov_b32 exec_hi, -1")
             self.lab(ll)
             self.i("s_waitcnt lgkmcnt(0)")
-            x = [16 + 4 * k for k in range(8)]                  # S buffer 0 is dead here: eight 16-byte read-back registers
-            for k in range(8):
+            NI = 32 // RPI
+            x = [16 + 4 * k for k in range(NI)]                 # S buffer 0 is dead here: the 16-byte read-back registers
+            for k in range(NI):
                 self.i(f"ds_read_b128 {vr(x[k], 4)}, {vr(rb[k & 3])} offset:{(k >> 2) * 4096}")
             if X == 'A':
                 self.i(f"s_mov_b32 {S('t0')}, 0")
             else:
                 self.i(f"s_lshl_b32 {S('t0')}, {ka('o_ss')}, 5")                   # strip B: 32 rows further
-            for k in range(8):
-                self.i(f"s_waitcnt lgkmcnt({7 - k})")
+            for k in range(NI):
+                self.i(f"s_waitcnt lgkmcnt({NI - 1 - k})")
                 self.i(f"buffer_store_dwordx4 {vr(x[k], 4)}, {vr(gofs)}, {S('osrd')}, {S('t0')} offen")
-                if k < 7:
+                if k < NI - 1:
                     self.i(f"s_add_u32 {S('t0')}, {S('t0')}, {S('t1')}")
         self.i(f"v_mov_b32 {vr(V_PS1)}, 0")
 
@@ -983,10 +1022,10 @@ class Gen:
         self.i(f"v_lshrrev_b32 {T1}, 5, {L}")                                       # h
         self.i(f"v_mul_lo_u32 {vr(gofs)}, {T0}, {ka('o_ss')}")
         self.i(f"v_lshl_add_u32 {vr(gofs)}, {T1}, 4, {vr(gofs)}")                   # r * o_ss + 16 h
-        self.i(f"s_lshr_b32 {S('t1')}, {S('w4k')}, 4")
+        self.i(f"s_lshl_b32 {S('t1')}, {S('wave')}, 8")
         self.i(f"v_lshlrev_b32 {T3}, 2, {T0}")
         self.i(f"v_add_u32 {T3}, {S('t1')}, {T3}")                                  # LSE offset (64 wave + r) * 4
-        self.i(f"s_lshr_b32 {S('t1')}, {S('w4k')}, 6")                              # 64 wave
+        self.i(f"s_lshl_b32 {S('t1')}, {S('wave')}, 6")                             # 64 wave
         self.i(f"s_mul_i32 {S('t1')}, {S('t1')}, {ka('o_ss')}")                     # the wave's first output row
         for X in "AB":
             l, mc = vr(STV(X, 'l')), vr(STV(X, 'mc'))
@@ -1002,12 +1041,12 @@ class Gen:
                 self.i(f"s_lshl_b32 {S('t0')}, {ka('o_ss')}, 5")
                 self.i(f"s_add_u32 {S('t1')}, {S('t1')}, {S('t0')}")                # strip B: 32 rows further
             n = 0
-            for db in range(4):
+            for db in range(self.DB):
                 for g in range(4):
                     w = V_E[4 * (n & 1):4 * (n & 1) + 4]     # two register quads in turn: a store's data is not overwritten right behind it
                     n += 1
                     for k in range(4):
-                        self.i(f"v_accvgpr_read_b32 {vr(w[k])}, a{OA(X, db, 4 * g + k)}")
+                        self.i(f"v_accvgpr_read_b32 {vr(w[k])}, a{self.OA(X, db, 4 * g + k)}")
                     for k in range(4):
                         self.i(f"v_mul_f32 {vr(w[k])}, {vr(w[k])}, {vr(inv)}")
                     self.i(f"buffer_store_dwordx4 {vr(w[0], 4)}, {vr(gofs)}, {S('osrd')}, {S('t1')} offen offset:{128 * db + 32 * g}")
@@ -1024,6 +1063,144 @@ class Gen:
             self.i("s_mov_b32 exec_hi, -1")
             self.lab(ll)
         self.i(f"v_mov_b32 {vr(V_PS1)}, 0")
+
+    def lane_constants_d128(self, L, T0, T1, T2, T3, W):
+        """LDS read addresses and DMA source offsets, D = 128 (one key per 256-B LDS row).  T0 = r, T1 = h on entry."""
+        # koff[ks] = r*256 + (((2ks+h) ^ sw(r)) << 4), sw(r) = ((r&3)<<2) | ((r>>2)&3)  ==  base ^ (32 ks)
+        self.i(f"v_and_b32 {T2}, 3, {T0}")
+        self.i(f"v_lshlrev_b32 {T2}, 2, {T2}")
+        self.i(f"v_bfe_u32 {T3}, {T0}, 2, 2")
+        self.i(f"v_or_b32 {T2}, {T2}, {T3}")
+        self.i(f"v_xor_b32 {T2}, {T2}, {T1}")
+        self.i(f"v_lshlrev_b32 {T2}, 4, {T2}")
+        self.i(f"v_lshl_add_u32 {T2}, {T0}, 8, {T2}")
+        for ks in range(8):
+            self.i(f"v_xor_b32 {vr(KOFF(ks))}, {32 * ks}, {T2}")
+        # voff[db][hi] = V_BASE + R*256 + ((ch ^ sw(R)) << 4) + 8 (tp&1);  R = 4h + tq + 8hi, ch = 4db + 2 g1 + (tp>>1),
+        # sw(R) = (tq << 2) | (h + 2 hi);  g1 = (lane>>4)&1, tq = (lane&15)>>2, tp = lane&3
+        e0, e1, e2, e3, e4 = (vr(x) for x in V_E[1:6])
+        self.i(f"v_bfe_u32 {e0}, {L}, 2, 2")                                      # tq
+        self.i(f"v_and_b32 {e1}, 3, {L}")                                         # tp
+        self.i(f"v_bfe_u32 {e2}, {L}, 4, 1")                                      # g1
+        self.i(f"v_lshrrev_b32 {e3}, 1, {e1}")
+        self.i(f"v_lshl_add_u32 {e3}, {e2}, 1, {e3}")                             # c2 = 2 g1 + (tp >> 1)
+        self.i(f"v_and_b32 {e1}, 1, {e1}")
+        self.i(f"v_lshlrev_b32 {e1}, 3, {e1}")                                    # 8 (tp & 1)
+        self.i(f"v_lshl_add_u32 {e4}, {T1}, 2, {e0}")                             # 4h + tq
+        for hi in range(2):
+            for db in range(4):
+                d = vr(VOFF(db, hi))
+                # ch ^ sw = ((db ^ tq) << 2) | (c2 ^ (h + 2 hi))
+                self.i(f"v_xor_b32 {T2}, {db}, {e0}")
+                self.i(f"v_add_u32 {T3}, {2 * hi}, {T1}")
+                self.i(f"v_xor_b32 {T3}, {T3}, {e3}")
+                self.i(f"v_lshl_add_u32 {T2}, {T2}, 2, {T3}")
+                self.i(f"v_lshlrev_b32 {T2}, 4, {T2}")
+                self.i(f"v_add_u32 {T3}, {8 * hi}, {e4}")                         # R
+                self.i(f"v_lshl_add_u32 {T2}, {T3}, 8, {T2}")
+                self.i(f"v_add_u32 {T2}, {T2}, {e1}")
+                self.i(f"v_add_u32 {d}, {self.V_BASE}, {T2}")
+        # DMA source offsets: row R = 16 wave + 4 t + q4 -> R * ss + ((c16 ^ ((q4 << 2) | t)) << 4) - 1024 t
+        self.i(f"v_lshrrev_b32 {e0}, 4, {L}")                                     # q4
+        self.i(f"v_and_b32 {e1}, 15, {L}")                                        # c16
+        self.i(f"s_lshl_b32 {S('t0')}, {W}, 4")
+        self.i(f"s_lshl_b32 {S('t1')}, {W}, 6")
+        for t in range(4):
+            self.i(f"v_lshl_or_b32 {e2}, {e0}, 2, {t}")
+            self.i(f"v_xor_b32 {e2}, {e2}, {e1}")
+            self.i(f"v_lshlrev_b32 {e2}, 4, {e2}")
+            self.i(f"v_add_u32 {e3}, {4 * t}, {e0}")
+            self.i(f"v_add_u32 {e3}, {S('t0')}, {e3}")                            # R
+            for d, ss in ((KDOFF(t), 'k_ss'), (VDOFF(t), 'v_ss')):
+                self.i(f"v_mul_lo_u32 {e4}, {e3}, {ka(ss)}")
+                self.i(f"v_add_u32 {e4}, {e4}, {e2}")
+                self.i(f"v_subrev_u32 {vr(d)}, {1024 * t}, {e4}")
+            # Q: row-in-16 = 4 t + q4 -> (64 wave + 4t + q4) * q_ss + ((c16 ^ (4t + q4)) << 4) - 1024 t
+            self.i(f"v_add_u32 {e3}, {4 * t}, {e0}")
+            self.i(f"v_xor_b32 {e2}, {e3}, {e1}")
+            self.i(f"v_lshlrev_b32 {e2}, 4, {e2}")
+            self.i(f"v_add_u32 {e3}, {S('t1')}, {e3}")                            # + the wave's first row of the block (64 wave)
+            self.i(f"v_mul_lo_u32 {e4}, {e3}, {ka('q_ss')}")
+            self.i(f"v_add_u32 {e4}, {e4}, {e2}")
+            self.i(f"v_subrev_u32 {vr(QDOFF(t))}, {1024 * t}, {e4}")
+
+    def tile_off64(self, dst, key, ch, t0, t1):
+        """dst = byte offset of 16-byte chunk ch of key `key` in a D = 64 tile image: two keys per 256-B LDS row R = key >> 1 (the odd
+        key in the upper half), position (((key & 1) << 3) | ch) ^ sw(R), sw(R) = ((R & 3) << 2) | ((R >> 2) & 3).  key / ch / dst / t0 /
+        t1: VGPR names; dst may be key or ch."""
+        self.i(f"v_lshrrev_b32 {t0}, 1, {key}")                                   # R
+        self.i(f"v_and_b32 {t1}, 1, {key}")
+        self.i(f"v_lshl_or_b32 {t1}, {t1}, 3, {ch}")                              # c
+        self.i(f"v_and_b32 {dst}, 3, {t0}")
+        self.i(f"v_lshlrev_b32 {dst}, 2, {dst}")
+        self.i(f"v_xor_b32 {t1}, {t1}, {dst}")
+        self.i(f"v_bfe_u32 {dst}, {t0}, 2, 2")
+        self.i(f"v_xor_b32 {t1}, {t1}, {dst}")                                    # c ^ sw
+        self.i(f"v_lshlrev_b32 {t1}, 4, {t1}")
+        self.i(f"v_lshl_add_u32 {dst}, {t0}, 8, {t1}")
+
+    def lane_constants_d64(self, L, T0, T1, T2, T3, W):
+        """LDS read addresses and DMA source offsets, D = 64 (two keys per 256-B LDS row, see tile_off64).  T0 = r, T1 = h on entry."""
+        e0, e1, e2, e3, e4, e5, e6 = (vr(x) for x in V_E[1:8])
+        # koff[ks] = off(r, 2 ks + h) = off(r, h) ^ (32 ks)
+        self.tile_off64(T2, T0, T1, T3, e0)
+        for ks in range(self.KS):
+            self.i(f"v_xor_b32 {vr(KOFF(ks))}, {32 * ks}, {T2}")
+        # voff[2 s2 + db][hi] = V_BASE + off(16 s2 + 8 hi + 4 h + tq, 4 db + 2 g1 + (tp >> 1)) + 8 (tp & 1)
+        self.i(f"v_bfe_u32 {e0}, {L}, 2, 2")                                      # tq
+        self.i(f"v_and_b32 {e1}, 3, {L}")                                         # tp
+        self.i(f"v_bfe_u32 {e2}, {L}, 4, 1")                                      # g1
+        self.i(f"v_lshrrev_b32 {e3}, 1, {e1}")
+        self.i(f"v_lshl_add_u32 {e3}, {e2}, 1, {e3}")                             # c2 = 2 g1 + (tp >> 1)
+        self.i(f"v_and_b32 {e1}, 1, {e1}")
+        self.i(f"v_lshlrev_b32 {e1}, 3, {e1}")                                    # 8 (tp & 1)
+        self.i(f"v_lshl_add_u32 {e4}, {T1}, 2, {e0}")                             # 4h + tq
+        for s2 in range(2):
+            for db in range(2):
+                for hi in range(2):
+                    d = vr(VOFF(2 * s2 + db, hi))
+                    self.i(f"v_add_u32 {e5}, {16 * s2 + 8 * hi}, {e4}")           # key
+                    self.i(f"v_add_u32 {e6}, {4 * db}, {e3}")                     # chunk
+                    self.tile_off64(e5, e5, e6, T2, T3)
+                    self.i(f"v_add_u32 {e5}, {e5}, {e1}")
+                    self.i(f"v_add_u32 {d}, {self.V_BASE}, {e5}")
+        # DMA source offsets.  A piece is 1 KiB = 4 LDS rows; lane (q4 = lane >> 4, c16 = lane & 15) fills position c16 of LDS row
+        # Rl = 8 wave + 4 t + q4 of the image, which holds c = c16 ^ sw(Rl), sw = (q4 << 2) | ((2 wave + t) & 3): chunk c & 7 of key
+        # 2 Rl + (c >> 3)  ->  key * ss + ((c & 7) << 4) - 1024 t  (the instruction's immediate adds 1024 t to both addresses)
+        self.i(f"v_lshrrev_b32 {e0}, 4, {L}")                                     # q4
+        self.i(f"v_and_b32 {e1}, 15, {L}")                                        # c16
+        for t in range(self.PPW):
+            self.i(f"s_lshl_b32 {S('t0')}, {W}, 1")
+            self.i(f"s_add_u32 {S('t0')}, {S('t0')}, {t}")
+            self.i(f"s_and_b32 {S('t0')}, {S('t0')}, 3")
+            self.i(f"v_lshl_or_b32 {e2}, {e0}, 2, {S('t0')}")                     # sw
+            self.i(f"v_xor_b32 {e2}, {e2}, {e1}")                                 # c
+            self.i(f"s_lshl_b32 {S('t0')}, {W}, 3")
+            self.i(f"s_add_u32 {S('t0')}, {S('t0')}, {4 * t}")
+            self.i(f"v_add_u32 {e3}, {S('t0')}, {e0}")                            # Rl
+            self.i(f"v_lshrrev_b32 {e4}, 3, {e2}")
+            self.i(f"v_lshl_add_u32 {e3}, {e3}, 1, {e4}")                         # key
+            self.i(f"v_and_b32 {e2}, 7, {e2}")
+            self.i(f"v_lshlrev_b32 {e2}, 4, {e2}")                                # 16 (c & 7)
+            for d, ss in ((KDOFF(t), 'k_ss'), (VDOFF(t), 'v_ss')):
+                self.i(f"v_mul_lo_u32 {e4}, {e3}, {ka(ss)}")
+                self.i(f"v_add_u32 {e4}, {e4}, {e2}")
+                self.i(f"v_subrev_u32 {vr(d)}, {1024 * t}, {e4}")
+        # Q: a group of four pieces is one strip (16 LDS rows = 32 query rows): piece t, lane (q4, c16) -> LDS row Rl = 4 t + q4,
+        # c = c16 ^ ((q4 << 2) | t): chunk c & 7 of row 64 wave + 2 Rl + (c >> 3) of the block (the second group: qoff + 32 rows)
+        self.i(f"s_lshl_b32 {S('t1')}, {W}, 6")
+        for t in range(4):
+            self.i(f"v_lshl_or_b32 {e2}, {e0}, 2, {t}")
+            self.i(f"v_xor_b32 {e2}, {e2}, {e1}")                                 # c
+            self.i(f"v_add_u32 {e3}, {4 * t}, {e0}")                              # Rl
+            self.i(f"v_lshrrev_b32 {e4}, 3, {e2}")
+            self.i(f"v_lshl_add_u32 {e3}, {e3}, 1, {e4}")                         # row in the strip
+            self.i(f"v_add_u32 {e3}, {S('t1')}, {e3}")
+            self.i(f"v_and_b32 {e2}, 7, {e2}")
+            self.i(f"v_lshlrev_b32 {e2}, 4, {e2}")
+            self.i(f"v_mul_lo_u32 {e4}, {e3}, {ka('q_ss')}")
+            self.i(f"v_add_u32 {e4}, {e4}, {e2}")
+            self.i(f"v_subrev_u32 {vr(QDOFF(t))}, {1024 * t}, {e4}")
 
     # ---- the kernel --------------------------------------------------------------------------------------------------------------
     def kernel(self):
@@ -1049,7 +1226,7 @@ class Gen:
         self.i(f"s_mul_i32 {S('Ux')}, {ka('hx')}, {ka('NU')}")
         self.i(f"s_lshl_b32 {S('ktile')}, {ka('k_ss')}, 6")
         self.i(f"s_lshl_b32 {S('vtile')}, {ka('v_ss')}, 6")
-        self.i(f"s_lshl_b32 {S('w4k')}, {W}, 12")
+        self.i(f"s_lshl_b32 {S('w4k')}, {W}, {12 if self.D == 128 else 11}")         # the wave's quarter of a tile image
         # constant descriptor words: records = bytes of one (batch, head) slab / of one item's rows, flags = raw buffer
         for sr, ss, rows in (('ksrd', 'k_ss', 'Sk'), ('vsrd', 'v_ss', 'Sk'), ('qsrd_n', 'q_ss', None), ('osrd', 'o_ss', None)):
             if rows:
@@ -1057,74 +1234,21 @@ class Gen:
                 self.i(f"s_mul_i32 {S('t0')}, {S('t0')}, {ka(ss)}")
             else:
                 self.i(f"s_mul_i32 {S('t0')}, {ka(ss)}, 255")
-            self.i(f"s_add_u32 {S(sr, 2)}, {S('t0')}, {512 if (sr == 'osrd' and self.out32) else 256}")
+            self.i(f"s_add_u32 {S(sr, 2)}, {S('t0')}, {self.RB * (2 if (sr == 'osrd' and self.out32) else 1)}")
             self.i(f"s_mov_b32 {S(sr, 3)}, 0x00020000")
         self.i(f"s_mov_b32 {S('lsrd', 2)}, 1024")
         self.i(f"s_mov_b32 {S('lsrd', 3)}, 0x00020000")
         # -- lane constants
         self.i(f"v_and_b32 {T0}, 31, {L}")                                        # r
         self.i(f"v_lshrrev_b32 {T1}, 5, {L}")                                     # h
-        # koff[ks] = r*256 + (((2ks+h) ^ sw(r)) << 4), sw(r) = ((r&3)<<2) | ((r>>2)&3)  ==  base ^ (32 ks)
-        self.i(f"v_and_b32 {T2}, 3, {T0}")
-        self.i(f"v_lshlrev_b32 {T2}, 2, {T2}")
-        self.i(f"v_bfe_u32 {T3}, {T0}, 2, 2")
-        self.i(f"v_or_b32 {T2}, {T2}, {T3}")
-        self.i(f"v_xor_b32 {T2}, {T2}, {T1}")
-        self.i(f"v_lshlrev_b32 {T2}, 4, {T2}")
-        self.i(f"v_lshl_add_u32 {T2}, {T0}, 8, {T2}")
-        for ks in range(8):
-            self.i(f"v_xor_b32 {vr(KOFF(ks))}, {32 * ks}, {T2}")
         # causal threshold tA = r + 1 - 4h
         self.i(f"v_lshlrev_b32 {T2}, 2, {T1}")
         self.i(f"v_sub_u32 {vr(V_TA)}, {T0}, {T2}")
         self.i(f"v_add_u32 {vr(V_TA)}, 1, {vr(V_TA)}")
-        # voff[db][hi] = V_BASE + R*256 + ((ch ^ sw(R)) << 4) + 8 (tp&1);  R = 4h + tq + 8hi, ch = 4db + 2 g1 + (tp>>1),
-        # sw(R) = (tq << 2) | (h + 2 hi);  g1 = (lane>>4)&1, tq = (lane&15)>>2, tp = lane&3
-        e0, e1, e2, e3, e4 = (vr(x) for x in V_E[1:6])
-        self.i(f"v_bfe_u32 {e0}, {L}, 2, 2")                                      # tq
-        self.i(f"v_and_b32 {e1}, 3, {L}")                                         # tp
-        self.i(f"v_bfe_u32 {e2}, {L}, 4, 1")                                      # g1
-        self.i(f"v_lshrrev_b32 {e3}, 1, {e1}")
-        self.i(f"v_lshl_add_u32 {e3}, {e2}, 1, {e3}")                             # c2 = 2 g1 + (tp >> 1)
-        self.i(f"v_and_b32 {e1}, 1, {e1}")
-        self.i(f"v_lshlrev_b32 {e1}, 3, {e1}")                                    # 8 (tp & 1)
-        self.i(f"v_lshl_add_u32 {e4}, {T1}, 2, {e0}")                             # 4h + tq
-        for hi in range(2):
-            for db in range(4):
-                d = vr(VOFF(db, hi))
-                # ch ^ sw = ((db ^ tq) << 2) | (c2 ^ (h + 2 hi))
-                self.i(f"v_xor_b32 {T2}, {db}, {e0}")
-                self.i(f"v_add_u32 {T3}, {2 * hi}, {T1}")
-                self.i(f"v_xor_b32 {T3}, {T3}, {e3}")
-                self.i(f"v_lshl_add_u32 {T2}, {T2}, 2, {T3}")
-                self.i(f"v_lshlrev_b32 {T2}, 4, {T2}")
-                self.i(f"v_add_u32 {T3}, {8 * hi}, {e4}")                         # R
-                self.i(f"v_lshl_add_u32 {T2}, {T3}, 8, {T2}")
-                self.i(f"v_add_u32 {T2}, {T2}, {e1}")
-                self.i(f"v_add_u32 {d}, {V_BASE}, {T2}")
-        # DMA source offsets: row R = 16 wave + 4 t + q4 -> R * ss + ((c16 ^ ((q4 << 2) | t)) << 4) - 1024 t
-        self.i(f"v_lshrrev_b32 {e0}, 4, {L}")                                     # q4
-        self.i(f"v_and_b32 {e1}, 15, {L}")                                        # c16
-        self.i(f"s_lshl_b32 {S('t0')}, {W}, 4")
-        self.i(f"s_lshl_b32 {S('t1')}, {W}, 6")
-        for t in range(4):
-            self.i(f"v_lshl_or_b32 {e2}, {e0}, 2, {t}")
-            self.i(f"v_xor_b32 {e2}, {e2}, {e1}")
-            self.i(f"v_lshlrev_b32 {e2}, 4, {e2}")
-            self.i(f"v_add_u32 {e3}, {4 * t}, {e0}")
-            self.i(f"v_add_u32 {e3}, {S('t0')}, {e3}")                            # R
-            for d, ss in ((KDOFF(t), 'k_ss'), (VDOFF(t), 'v_ss')):
-                self.i(f"v_mul_lo_u32 {e4}, {e3}, {ka(ss)}")
-                self.i(f"v_add_u32 {e4}, {e4}, {e2}")
-                self.i(f"v_subrev_u32 {vr(d)}, {1024 * t}, {e4}")
-            # Q: row-in-16 = 4 t + q4 -> (64 wave + 4t + q4) * q_ss + ((c16 ^ (4t + q4)) << 4) - 1024 t
-            self.i(f"v_add_u32 {e3}, {4 * t}, {e0}")
-            self.i(f"v_xor_b32 {e2}, {e3}, {e1}")
-            self.i(f"v_lshlrev_b32 {e2}, 4, {e2}")
-            self.i(f"v_add_u32 {e3}, {S('t1')}, {e3}")                            # + the wave's first row of the block (64 wave)
-            self.i(f"v_mul_lo_u32 {e4}, {e3}, {ka('q_ss')}")
-            self.i(f"v_add_u32 {e4}, {e4}, {e2}")
-            self.i(f"v_subrev_u32 {vr(QDOFF(t))}, {1024 * t}, {e4}")
+        if self.D == 128:
+            self.lane_constants_d128(L, T0, T1, T2, T3, W)
+        else:
+            self.lane_constants_d64(L, T0, T1, T2, T3, W)
         # -- first item: decode, fetch its Q block, K0, then V0 and K1
         self.i(f"s_mov_b32 {S('n_u')}, 0")
         self.i(f"s_mov_b32 {S('n_sub')}, 0")
@@ -1133,10 +1257,10 @@ class Gen:
         self.i(f"s_cmp_eq_u32 {S('n_valid')}, 0")
         self.i(f"s_cbranch_scc1 {lend}")
         self.i(f"s_lshl_b32 {S('qdst')}, {S('w4k')}, 2")
-        self.i(f"s_add_u32 {S('qdst')}, {S('qdst')}, {Q_BASE}")
+        self.i(f"s_add_u32 {S('qdst')}, {S('qdst')}, {self.Q_BASE}")
         self.i(f"s_mov_b32 {S('qoff')}, 0")
-        self.i(f"s_mov_b32 {S('qrem')}, 4")
-        for g in range(4):
+        self.i(f"s_mov_b32 {S('qrem')}, {self.PPW}")
+        for g in range(self.PPW):                # the wave's 64 rows, 4 KiB a group
             self.q_group()
         self.i(f"s_mov_b64 {S('ksrd', 0, 2)}, {S('ksrd_n')}")
         self.i(f"s_mov_b64 {S('vsrd', 0, 2)}, {S('vsrd_n')}")
@@ -1144,20 +1268,20 @@ class Gen:
         self.i(f"s_mov_b32 {S('voff')}, 0")
         self.i(self.setm0('k', 0))
         self.i("s_nop 0")
-        for t in range(4):
+        for t in range(self.PPW):
             self.i(self.dma('K', t))
         self.i(self.setm0('v', 0))
         self.i("s_nop 0")
-        for t in range(4):
+        for t in range(self.PPW):
             self.i(self.dma('V', t))
         self.i(f"s_add_u32 {S('koff')}, {S('koff')}, {S('ktile')}")
         self.i(self.setm0('k', 1))
         self.i("s_nop 0")
-        for t in range(4):
+        for t in range(self.PPW):
             self.i(self.dma('K', t))
         self.i(f"s_add_u32 {S('koff')}, {S('koff')}, {S('ktile')}")               # next K piece: tile 2
         self.i(f"s_add_u32 {S('voff')}, {S('voff')}, {S('vtile')}")               # next V piece: tile 1
-        self.i("s_waitcnt vmcnt(8)")                                              # Q and K0 (V0, K1 are the eight youngest)
+        self.i(f"s_waitcnt vmcnt({2 * self.PPW})")                                # Q and K0 (the pieces of V0, K1 are the youngest)
         self.i("s_barrier")
         litem = f".L{n}_item"
         self.lab(litem)
@@ -1180,9 +1304,9 @@ class Gen:
             self.i(f"s_add_u32 {S('n_u')}, {S('n_u')}, 1")
         self.decode()
         self.i(f"s_mov_b32 {S('nt_n')}, {S('n_nt')}")
-        self.i(f"s_lshl_b32 {S('qrem')}, {S('n_valid')}, 2")                      # 4 groups of Q pieces if there is a next item
+        self.i(f"s_lshl_b32 {S('qrem')}, {S('n_valid')}, {2 if self.PPW == 4 else 1}")   # PPW groups of Q pieces if there is a next item
         self.i(f"s_lshl_b32 {S('qdst')}, {S('w4k')}, 2")
-        self.i(f"s_add_u32 {S('qdst')}, {S('qdst')}, {Q_BASE}")
+        self.i(f"s_add_u32 {S('qdst')}, {S('qdst')}, {self.Q_BASE}")
         self.i(f"s_mov_b32 {S('qoff')}, 0")
         self.item_prologue()
         self.i("s_waitcnt vmcnt(0)")
@@ -1229,7 +1353,7 @@ class Gen:
 	.section	.rodata,"a",@progbits
 	.p2align	6, 0x0
 	.amdhsa_kernel {n}
-		.amdhsa_group_segment_fixed_size {LDS_BYTES}
+		.amdhsa_group_segment_fixed_size {self.LDS_BYTES}
 		.amdhsa_private_segment_fixed_size 0
 		.amdhsa_kernarg_size {4 * KARG_DWORDS}
 		.amdhsa_user_sgpr_count 2
@@ -1261,7 +1385,7 @@ class Gen:
       - .offset:         0
         .size:           {4 * KARG_DWORDS}
         .value_kind:     by_value
-    .group_segment_fixed_size: {LDS_BYTES}
+    .group_segment_fixed_size: {self.LDS_BYTES}
     .kernarg_segment_align: 8
     .kernarg_segment_size: {4 * KARG_DWORDS}
     .max_flat_workgroup_size: 256
@@ -1280,7 +1404,7 @@ class Gen:
 
 def kernels():
     """(dtype, causal, parity): parity = fp32 store + split P (the <= 1e-3 variant on the same schedule)"""
-    return [(dt, causal, par) for dt in ("bf16", "fp16") for causal in (True, False) for par in (False, True)]
+    return [(dt, D, causal, par) for dt in ("bf16", "fp16") for D in (128, 64) for causal in (True, False) for par in (False, True)]
 
 
 def main():
@@ -1288,12 +1412,13 @@ def main():
         for k, v in KA.items():
             print(f"#define P4_KA_{k.upper()} {4 * v}")
         print(f"#define P4_KARG_BYTES {4 * KARG_DWORDS}")
-        print(f"#define P4_LDS_BYTES {LDS_BYTES}")
+        print(f"#define P4_LDS_BYTES_D128 {10 * 128 * 128}")
+        print(f"#define P4_LDS_BYTES_D64 {10 * 128 * 64}")
         return
     out = ['\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', "\t.amdhsa_code_object_version 6", "\t.text"]
     meta = []
-    for dt, causal, par in kernels():
-        g = Gen(dt, causal, out32=par, split=par)
+    for dt, D, causal, par in kernels():
+        g = Gen(dt, causal, out32=par, split=par, D=D)
         g.kernel()
         out += g.main
         out.append(g.descriptor())

@@ -89,7 +89,7 @@ Variant exp_variant(bool causal) {
 Variant p4_variant(const pfa_fa3_args* a, bool causal) {
     Variant v;
     v.fn = nullptr;
-    snprintf(v.name, sizeof(v.name), "fa3_fwd_p4_%s_d128_%s_%s", a->dtype_in == PFA_DTYPE_BF16 ? "bf16" : "fp16", causal ? "causal" : "full",
+    snprintf(v.name, sizeof(v.name), "fa3_fwd_p4_%s_d%d_%s_%s", a->dtype_in == PFA_DTYPE_BF16 ? "bf16" : "fp16", a->D, causal ? "causal" : "full",
              a->dtype_out == PFA_DTYPE_FP32 ? "splitp_o32" : "o16");
     v.p4 = true;
     v.p4_grid = pfa::p4_workgroups(a);
@@ -133,7 +133,12 @@ Variant pick(const pfa_fa3_args* a) {
     // +24 %, S2048 causal +12 %: profiles/r02_p4_experiments.txt); the 4-wave HIP kernel keeps the other long problems.
     if (pfa::p4_eligible(a) && (var == 45 || var == 0)) {
         Variant v = p4_variant(a, causal);
-        if (v.p4_grid > 0) return v;           // (0: the code object did not load on this device -- fall through to the HIP kernels)
+        // D = 64: the tile loop is bound by the softmax's vector instructions (half the MFMA work under the same exponentials), where
+        // two waves per SIMD (the 8-wave HIP kernel) overlap better than one: the persistent kernel only wins while every unit has a CU
+        // of its own, i.e. no item seam (same box: C2 +3 %, 256 units +2 %; 384 units -9 %, 1024 units -8 %).  Selector 45 forces it.
+        const int64_t units = (int64_t)a->B * a->H * (a->Sq / 256) / (causal ? 2 : 1);
+        const bool take = a->D == 128 || var == 45 || units <= v.p4_grid;
+        if (v.p4_grid > 0 && take) return v;   // (0: the code object did not load on this device -- fall through to the HIP kernels)
     }
 #ifdef PFA_DEV_VARIANTS
     if (w4_ok && (var == 47 || var == 48 || var == 49)) {      // A/B: head-grouped block order 2 / 4 / off

@@ -56,7 +56,7 @@ namespace {
 constexpr int MAX_DEV = 64;
 struct DevMod {
     hipModule_t mod = nullptr;
-    hipFunction_t fn[2][2][2] = {};  // [dtype][causal][parity variant: fp32 store + split P]
+    hipFunction_t fn[2][2][2][2] = {};  // [dtype][D: 128, 64][causal][parity variant: fp32 store + split P]
     int n_cu = 0;
     int state = 0;                   // 0 = not tried, 1 = ready, -1 = failed
 };
@@ -86,12 +86,13 @@ const DevMod* module_for(int dev) {
         static const char* cz[2] = {"full", "causal"};
         static const char* pv[2] = {"o16", "splitp_o32"};
         for (int d = 0; d < 2; ++d)
-            for (int c = 0; c < 2; ++c)
-                for (int v = 0; v < 2; ++v) {
-                    char name[64];
-                    snprintf(name, sizeof(name), "fa3_fwd_p4_%s_%s_%s", dt[d], cz[c], pv[v]);
-                    if (hipModuleGetFunction(&m.fn[d][c][v], m.mod, name) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-                }
+            for (int hd = 0; hd < 2; ++hd)
+                for (int c = 0; c < 2; ++c)
+                    for (int v = 0; v < 2; ++v) {
+                        char name[64];
+                        snprintf(name, sizeof(name), "fa3_fwd_p4_%s_d%d_%s_%s", dt[d], hd ? 64 : 128, cz[c], pv[v]);
+                        if (hipModuleGetFunction(&m.fn[d][hd][c][v], m.mod, name) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+                    }
         m.state = 1;
     }
     return m.state == 1 ? &m : nullptr;
@@ -100,13 +101,13 @@ const DevMod* module_for(int dev) {
 bool fits_u32(int64_t x) { return x >= 0 && x <= 0xffffffffLL; }
 }  // namespace
 
-// Shapes the persistent kernel takes (everything else stays on the HIP kernels): D = 128; the fast variant (one P operand, 16-bit
+// Shapes the persistent kernel takes (everything else stays on the HIP kernels): D = 128 or 64; the fast variant (one P operand, 16-bit
 // store) or the parity variant (split P AND fp32 store); no mask / seqlens, whole 256-row Q blocks and an even number of 64-key
 // tiles (the two S buffers alternate from tile 0 of every item), at least 4 tiles; under the causal mask Sq == Sk and an even
 // number of Q blocks (units are heavy + light block pairs).
 bool p4_eligible(const pfa_fa3_args* a) {
     const bool split = (a->flags & PFA_FLAG_SPLIT_P) != 0, out32 = a->dtype_out == PFA_DTYPE_FP32;
-    if (a->D != 128 || split != out32) return false;
+    if ((a->D != 128 && a->D != 64) || split != out32) return false;
     const int64_t osz = out32 ? 4 : 2;
     if (a->key_mask || a->mask || a->seqlens_k) return false;
     if (a->Sq % 256 != 0 || a->Sk % 128 != 0 || a->Sk < 256) return false;
@@ -116,8 +117,8 @@ bool p4_eligible(const pfa_fa3_args* a) {
     for (int64_t s : st)
         if (!fits_u32(s * 2)) return false;
     if (!fits_u32(a->o_stride_b * osz) || !fits_u32(a->o_stride_h * osz) || !fits_u32(a->o_stride_s * osz)) return false;
-    // row strides: a wave's DMA offsets (row * stride + 256) and an item's output rows stay below 2^31; rows at least 256 B apart
-    if (a->q_stride_s < 128 || a->k_stride_s < 128 || a->v_stride_s < 128 || a->o_stride_s < 128) return false;
+    // row strides: a wave's DMA offsets (row * stride + 256) and an item's output rows stay below 2^31; rows at least D elements apart
+    if (a->q_stride_s < a->D || a->k_stride_s < a->D || a->v_stride_s < a->D || a->o_stride_s < a->D) return false;
     if ((int64_t)a->Sk * a->k_stride_s * 2 > 0x7fffffffLL || (int64_t)a->Sk * a->v_stride_s * 2 > 0x7fffffffLL) return false;
     if (256 * a->q_stride_s * 2 > 0x7fffffffLL || 256 * a->o_stride_s * osz > 0x7fffffffLL) return false;
     if ((a->o_stride_s * osz) % 16 != 0 || (a->o_stride_h * osz) % 16 != 0 || (a->o_stride_b * osz) % 16 != 0 ||
@@ -166,7 +167,7 @@ int p4_launch(const pfa_fa3_args* a, void* stream, int* hip_err) {
 
     size_t sz = sizeof(p);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-    hipFunction_t fn = m->fn[a->dtype_in == PFA_DTYPE_BF16 ? 0 : 1][a->causal ? 1 : 0][parity ? 1 : 0];
+    hipFunction_t fn = m->fn[a->dtype_in == PFA_DTYPE_BF16 ? 0 : 1][a->D == 64 ? 1 : 0][a->causal ? 1 : 0][parity ? 1 : 0];
     int prev = -1;
     hipError_t e = hipGetDevice(&prev);
     if (e == hipSuccess && prev != a->device_id) e = hipSetDevice(a->device_id);

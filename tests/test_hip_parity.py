@@ -384,6 +384,12 @@ P4_CASES = [
     (1, 16, 2048, 2048, True, 4),       # grouped-query heads
     (2, 16, 1024, 2304, False, 2),      # cross attention, long keys, GQA
     (9, 32, 256, 384, False, 32),       # more units than workgroups
+    # head dim 64 (two keys per LDS row, half the fragments per tile): the last element is D
+    (1, 8, 512, 512, True, 8, 64),
+    (4, 12, 1024, 1024, False, 12, 64),  # BASELINE configs[1] (C2)
+    (3, 5, 768, 640, False, 5, 64),
+    (1, 16, 2048, 2048, True, 4, 64),
+    (9, 32, 256, 384, False, 8, 64),
 ]
 
 
@@ -392,15 +398,16 @@ P4_CASES = [
 def test_p4_kernel_against_the_oracle_and_the_8_wave_kernel(case, dtype):
     from oracle import fa3_oracle as orc
     from photonic_flash_attention_amd import _capi, ops, synth
-    B, H, Sq, Sk, causal, Hkv = case
-    q, k, v = synth.qkv(B, H, Sq, Sk, 128, 4500 + Sq + H, dtype)
+    B, H, Sq, Sk, causal, Hkv = case[:6]
+    D = case[6] if len(case) > 6 else 128
+    q, k, v = synth.qkv(B, H, Sq, Sk, D, 4500 + Sq + H, dtype)
     k, v = k[:, :, :Hkv].contiguous(), v[:, :, :Hkv].contiguous()
     qd, kd, vd = (t.to("cuda:0").permute(0, 2, 1, 3) for t in (q, k, v))
     o45, l45 = ops.fa3_forward(qd, kd, vd, causal=causal, return_lse=True, _variant=45)
     o44, l44 = ops.fa3_forward(qd, kd, vd, causal=causal, return_lse=True, _variant=44)
     torch.cuda.synchronize()
     name = _capi.describe(ops.build_args(qd, kd, vd, o45, causal=causal, variant=45)[0])[0]
-    assert name.startswith("fa3_fwd_p4_"), name
+    assert name.startswith(f"fa3_fwd_p4_{dtype}_d{D}_"), name
     assert bool(torch.isfinite(o45.float()).all())
     assert float((o45.float() - o44.float()).abs().max()) <= float(o44.float().abs().max()) * 2.0 ** (-8 if dtype == "bf16" else -10)
     assert float((l45 - l44).abs().max()) <= 2e-5
@@ -441,6 +448,11 @@ def test_p4_kernel_reads_fused_qkv_views_and_is_the_default_for_long_aligned_pro
     assert _capi.describe(ops.build_args(q, k, v, o32, causal=False, split_p=True)[0])[0] == "fa3_fwd_p4_bf16_d128_full_splitp_o32"
     assert "p4" not in _capi.describe(ops.build_args(q, k, v, o32, causal=False, split_p=False)[0])[0]      # fp32 store, one P: HIP kernel
     assert "p4" not in _capi.describe(ops.build_args(q, k, v, out, causal=False, seqlens_k=[S, S - 1])[0])[0]
+    # D = 64 (softmax-bound: two waves per SIMD overlap better): only while every unit has a CU of its own -- C2 yes, 16 x 16 x 2048 no
+    for (b, h, s, want) in ((4, 12, 1024, True), (16, 16, 2048, False)):
+        t = torch.empty(b, s, h, 64, device="cuda:0", dtype=torch.bfloat16).permute(0, 2, 1, 3)
+        nm = _capi.describe(ops.build_args(t, t, t, torch.empty_like(t), causal=False)[0])[0]
+        assert nm.startswith("fa3_fwd_p4_bf16_d64_full") == want, (b, h, s, nm)
 
 
 def test_p4_kernel_random_eligible_shapes():
@@ -456,11 +468,12 @@ def test_p4_kernel_random_eligible_shapes():
         else:
             Sq, Sk = 256 * rnd.randint(1, 6), 128 * rnd.randint(2, 12)
         dtype = rnd.choice(["bf16", "fp16"])
-        q, k, v = (t.to("cuda:0").permute(0, 2, 1, 3) for t in synth.qkv(B, H, Sq, Sk, 128, 12000 + it, dtype))
+        D = rnd.choice([128, 64])
+        q, k, v = (t.to("cuda:0").permute(0, 2, 1, 3) for t in synth.qkv(B, H, Sq, Sk, D, 12000 + it, dtype))
         o0, l0 = ops.fa3_forward(q, k, v, causal=causal, return_lse=True, _variant=44)
         o1, l1 = ops.fa3_forward(q, k, v, causal=causal, return_lse=True, _variant=45)
         torch.cuda.synchronize()
-        tag = (it, B, H, Sq, Sk, causal, dtype)
+        tag = (it, B, H, Sq, Sk, D, causal, dtype)
         assert bool(torch.isfinite(o1.float()).all()), tag
         assert float((o0.float() - o1.float()).abs().max()) <= float(o0.float().abs().max()) * 2.0 ** (-8 if dtype == "bf16" else -10), tag
         assert float((l0 - l1).abs().max()) <= 3e-5, tag

@@ -10,22 +10,26 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--time", action="store_true")
 ap.add_argument("--shapes", default="small")
 ap.add_argument("--dtype", default="bf16")
+ap.add_argument("--d", type=int, default=128)
+ap.add_argument("--tshapes", default="big")
 a = ap.parse_args()
+D = a.d
 dev = torch.device("cuda:0")
 dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
 SHAPES = {
     "small": [(1, 8, 512, True), (1, 8, 256, False), (1, 8, 512, False), (2, 4, 1024, True), (1, 3, 512, True), (3, 5, 768, False),
               (1, 16, 2048, True), (2, 16, 1024, False)],
     "big": [(4, 16, 4096, True), (4, 16, 4096, False), (1, 32, 16384, True), (16, 16, 2048, False)],
+    "c2": [(4, 12, 1024, False), (4, 16, 1024, False), (8, 12, 1024, False), (4, 12, 2048, False), (4, 12, 2048, True), (16, 16, 2048, False), (4, 16, 4096, True)],
 }
 bad = 0
 for (B, H, S, causal) in SHAPES[a.shapes]:
     g = torch.Generator(device=dev).manual_seed(B * 1000 + H * 10 + S)
-    q, k, v = (torch.randn(B, S, H, 128, device=dev, dtype=torch.float32, generator=g).to(dt) for _ in range(3))
+    q, k, v = (torch.randn(B, S, H, D, device=dev, dtype=torch.float32, generator=g).to(dt) for _ in range(3))
     qv, kv, vv = (t.permute(0, 2, 1, 3) for t in (q, k, v))
     res = {}
     for var in (44, 45):
-        out = torch.full((B, S, H, 128), float("nan"), device=dev, dtype=dt).permute(0, 2, 1, 3)
+        out = torch.full((B, S, H, D), float("nan"), device=dev, dtype=dt).permute(0, 2, 1, 3)
         o, lse = ops.fa3_forward(qv, kv, vv, causal=causal, out=out, return_lse=True, _variant=var)
         torch.cuda.synchronize()
         res[var] = (o.float().clone(), lse.clone())
@@ -38,7 +42,7 @@ for (B, H, S, causal) in SHAPES[a.shapes]:
     # the parity variant (fp32 store + split P) on the same schedule
     r32 = {}
     for var in (44, 45):
-        o32 = torch.full((B, S, H, 128), float("nan"), device=dev, dtype=torch.float32).permute(0, 2, 1, 3)
+        o32 = torch.full((B, S, H, D), float("nan"), device=dev, dtype=torch.float32).permute(0, 2, 1, 3)
         o, lse = ops.fa3_forward(qv, kv, vv, causal=causal, out=o32, out_dtype=torch.float32, return_lse=True, _variant=var)
         torch.cuda.synchronize()
         r32[var] = (o.clone(), lse.clone())
@@ -57,12 +61,12 @@ for (B, H, S, causal) in SHAPES[a.shapes]:
         print("   first bad (b, h, 64-row block):", idx.tolist(), flush=True)
 print("FAILED" if bad else "ALL OK", flush=True)
 if a.time and not bad:
-    for (B, H, S, causal) in SHAPES["big"]:
-        q, k, v = (torch.randn(B, S, H, 128, device=dev, dtype=torch.float32).to(dt) for _ in range(3))
+    for (B, H, S, causal) in SHAPES[a.tshapes]:
+        q, k, v = (torch.randn(B, S, H, D, device=dev, dtype=torch.float32).to(dt) for _ in range(3))
         qv, kv, vv = (t.permute(0, 2, 1, 3) for t in (q, k, v))
-        out = torch.empty(B, S, H, 128, device=dev, dtype=dt).permute(0, 2, 1, 3)
-        fl = 4.0 * B * H * S * S * 128 / (2 if causal else 1)
-        times = {43: [], 45: []}
+        out = torch.empty(B, S, H, D, device=dev, dtype=dt).permute(0, 2, 1, 3)
+        fl = 4.0 * B * H * S * S * D / (2 if causal else 1)
+        times = {(43 if D == 128 else 44): [], 45: []}
         for var in times:
             for _ in range(20):
                 ops.fa3_forward(qv, kv, vv, causal=causal, out=out, _variant=var)
