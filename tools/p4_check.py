@@ -12,6 +12,7 @@ ap.add_argument("--shapes", default="small")
 ap.add_argument("--dtype", default="bf16")
 ap.add_argument("--d", type=int, default=128)
 ap.add_argument("--tshapes", default="big")
+ap.add_argument("--force-time", action="store_true")
 a = ap.parse_args()
 D = a.d
 dev = torch.device("cuda:0")
@@ -60,7 +61,7 @@ for (B, H, S, causal) in SHAPES[a.shapes]:
         idx = (eb > 2e-2).nonzero()[:12]
         print("   first bad (b, h, 64-row block):", idx.tolist(), flush=True)
 print("FAILED" if bad else "ALL OK", flush=True)
-if a.time and not bad:
+if a.time and (not bad or a.force_time):
     for (B, H, S, causal) in SHAPES[a.tshapes]:
         q, k, v = (torch.randn(B, S, H, D, device=dev, dtype=torch.float32).to(dt) for _ in range(3))
         qv, kv, vv = (t.permute(0, 2, 1, 3) for t in (q, k, v))
