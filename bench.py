@@ -297,6 +297,25 @@ def main():
                             "kernel": _capi.describe(ops.build_args(q2v, k2v, v2v, o2v, causal=c2)[0])[0],
                             "shape": f"B={b2} S={s2} H={h2} D={d2} {'causal' if c2 else 'non-causal'}"}
             del q2, k2, v2, o2
+        # a [B, Sk] key-padding mask on the same schedule (the *_km_* kernels read the mask bytes themselves): S = 2048, D = 128, lengths
+        # uniform in [S / 2, S]; dense-equivalent flops, next to the unmasked launch of the same shape
+        b2, h2, s2, d2 = 16, 16, 2048, 128
+        q2, k2, v2, o2 = make(b2, h2, s2, d2, 78)
+        q2v, k2v, v2v, o2v = (t.permute(0, 2, 1, 3) for t in (q2, k2, v2, o2))
+        lens = torch.randint(s2 // 2, s2 + 1, (b2,), generator=torch.Generator().manual_seed(79)).to(dev)
+        kmask = (torch.arange(s2, device=dev)[None, :] < lens[:, None]).to(torch.uint8)
+        for tag, kw in (("S2048", {}), ("S2048_key_mask", {"key_mask": kmask})):
+            def step3():
+                ops.fa3_forward(q2v, k2v, v2v, causal=False, out=o2v, **kw)
+            for _ in range(100):
+                step3()
+            w3, kk3 = timed(step3, args.steps, 3)
+            m3 = statistics.median(kk3)
+            others[tag] = {"ms": round(m3, 4), "tflops": round(flops(b2, h2, s2, d2, False) / (m3 * 1e-3) / 1e12, 2),
+                           "frac": round(flops(b2, h2, s2, d2, False) / (m3 * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                           "kernel": _capi.describe(ops.build_args(q2v, k2v, v2v, o2v, causal=False, **kw)[0])[0],
+                           "shape": f"B={b2} S={s2} H={h2} D={d2} non-causal" + (", key-padding mask (lengths in [S/2, S], dense-equivalent flops)" if kw else "")}
+        del q2, k2, v2, o2
 
     if rank == 0:
         name, nwg = _capi.describe(ops.build_args(qv, kv, vv, outv, causal=causal, variant=args.variant)[0])

@@ -155,11 +155,12 @@ class Lgkm:
 
 
 class Gen:
-    def __init__(self, dtype, causal, out32=False, split=False, D=128):
+    def __init__(self, dtype, causal, out32=False, split=False, D=128, kmask=False):
         """out32: fp32 store (straight from the accumulators); split: P enters the PV product as a 16-bit hi + lo pair (two MFMAs per
         fragment, P's rounding error 2^-18 instead of 2^-9): together the <= 1e-3 parity variant on the benched schedule."""
         assert out32 == split, "the code object carries the fast variant (16-bit store, one P) and the parity variant (fp32 store, split P)"
-        self.dt, self.causal, self.out32, self.split = dtype, causal, out32, split
+        self.dt, self.causal, self.out32, self.split, self.kmask = dtype, causal, out32, split, kmask
+        assert not (kmask and STAMP), "the key-mask kernels keep their mask words where the stamps keep their clock (s[58:59], the dbg kernarg)"
         assert D in (64, 128)
         self.D, self.KS, self.DB = D, D // 16, D // 32                 # head dim, k-steps of QK^T, 32-wide d blocks of PV
         self.NKF, self.NVF = 2 * self.KS, 4 * self.DB                   # K / V^T fragments per 64-key tile
@@ -172,7 +173,7 @@ class Gen:
         self.RING = min(RING, self.NKF)
         self.mf = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
-        self.name = f"fa3_fwd_p4_{dtype}_d{D}_{'causal' if causal else 'full'}_{'splitp_o32' if out32 else 'o16'}"
+        self.name = f"fa3_fwd_p4_{dtype}_d{D}_{'causal' if causal else 'full'}{'_km' if kmask else ''}_{'splitp_o32' if out32 else 'o16'}"
         self.main, self.ool = [], []
         self.L = self.main
         self.abl_on = False
@@ -274,6 +275,50 @@ class Gen:
             self.i(f"buffer_store_dword v{184 + k}, {t3}, {S('lsrd')}, {S('t0')} offen offset:{4 * k}")
         self.i("s_mov_b64 exec, -1")
         self.lab(lskip)
+
+    # ---- key mask (kmask kernels): the caller's [B, Sk] bytes (contiguous rows, non-zero = visible) at the `dbg` kernarg.  Every wave
+    # reads the 64 bytes of a tile itself (lane i: key 64 t + i, one global_load_ubyte) two tiles ahead, beside the K pieces of that
+    # tile and with the same stream switch; at the bottom of the iteration (behind its counted vmcnt) a compare turns them into the
+    # 64-bit word MK(t & 1): bit i = key 64 t + i visible.  `pad` = the running byte offset b * Sk + 64 t.
+    KM_V = [V_E[4], V_E[5]]                    # the bytes in flight (scratch registers nothing else touches inside the tile loop)
+
+    @staticmethod
+    def MK(i):
+        return "s[58:59]" if i == 0 else "s[100:101]"
+
+    def mask_load(self, n=0):
+        v = vr(self.KM_V[n])
+        return [f"v_add_u32 {v}, {ka('pad')}, {vr(V_LANE)}", f"global_load_ubyte {v}, {v}, {ka('dbg', 2)}"]
+
+    def mask_word(self, i, n=0):
+        return f"v_cmp_ne_u32_e64 {self.MK(i)}, 0, {vr(self.KM_V[n])}"
+
+    def mask_keys(self, buf, i):
+        """S of buffer `buf` (both strips) under the mask word MK(i): nothing to do when all 64 keys are visible (the common tile of a
+        padding mask), else -inf per masked key: key 32 kb + kidx(e) + 4 h of register e -- bit b for the lower lane half, b + 4 for the upper."""
+        if not self.kmask:
+            return
+        lm, lr = self.ul("kmask"), self.ul("kmasked")
+        self.i(f"s_cmp_eq_u64 {self.MK(i)}, -1")
+        self.i(f"s_cbranch_scc0 {lm}")
+        self.lab(lr)
+        self.out_of_line(True)
+        self.lab(lm)
+        self.i("s_nop 7")
+        self.i("s_nop 7")                     # last QK^T MFMA -> VALU access of S
+        ninf = vr(V_T[3])
+        self.i(f"v_mov_b32 {ninf}, {NEG_INF}")
+        for kb in range(2):
+            for e in range(16):
+                b = 32 * kb + (e & 3) + 8 * (e >> 2)
+                self.i(f"s_bitcmp1_b64 {self.MK(i)}, {b}")
+                self.i("s_cselect_b32 vcc_lo, -1, 0")
+                self.i(f"s_bitcmp1_b64 {self.MK(i)}, {b + 4}")
+                self.i("s_cselect_b32 vcc_hi, -1, 0")
+                for X in "AB":
+                    self.i(f"v_cndmask_b32 {vr(SBUF(buf, X, kb, e))}, {ninf}, {vr(SBUF(buf, X, kb, e))}, vcc")
+        self.i(f"s_branch {lr}")
+        self.out_of_line(False)
 
     # ---- building blocks -------------------------------------------------------------------------------------------------
     def kread(self, slot, i):                 # K fragment i = (kb, ks) of the K tile in ring slot `slot` -> ring register i % 4
@@ -515,14 +560,18 @@ class Gen:
         return lg
 
     # ---- DMA stream bookkeeping (top and bottom of every iteration, all body kinds; workgroup-uniform) -----------------------------
-    def stream_top(self):
+    def stream_top(self, p):
         l1, l2 = self.ul("kok"), self.ul("vok")
         self.i(f"s_cmp_lg_u32 {S('krem')}, 0")
         self.i(f"s_cbranch_scc1 {l1}")
         self.i(f"s_mov_b64 {S('ksrd', 0, 2)}, {S('ksrd_n')}")           # K(j+2) is tile 0 of the next item
         self.i(f"s_mov_b32 {S('koff')}, 0")
         self.i(f"s_mov_b32 {S('krem')}, {S('nt_n')}")
+        if self.kmask:                                                  # ... and so are its mask bytes: row n_b
+            self.i(f"s_mul_i32 {ka('pad')}, {S('n_b')}, {ka('Sk')}")
         self.lab(l1)
+        if self.kmask:
+            self.emit(self.mask_load())                                 # the bytes of tile j+2 (its K pieces go to slot p in this iteration)
         self.i(f"s_cmp_lg_u32 {S('vrem')}, 0")
         self.i(f"s_cbranch_scc1 {l2}")
         self.i(f"s_mov_b64 {S('vsrd', 0, 2)}, {S('vsrd_n')}")
@@ -530,7 +579,7 @@ class Gen:
         self.i(f"s_mov_b32 {S('vrem')}, {S('nt_n')}")
         self.lab(l2)
 
-    def stream_bottom(self):
+    def stream_bottom(self, p):
         """Q pieces of the next item (first four iterations of an item), the counted wait, the barrier."""
         lq, lb = self.ul("q"), self.ul("bar")
         self.i(f"s_add_u32 {S('koff')}, {S('koff')}, {S('ktile')}")
@@ -538,12 +587,16 @@ class Gen:
         self.i(f"s_sub_u32 {S('krem')}, {S('krem')}, 1")
         self.i(f"s_sub_u32 {S('vrem')}, {S('vrem')}, 1")
         self.i(f"s_sub_u32 {S('wrem')}, {S('wrem')}, 1")
+        if self.kmask:
+            self.i(f"s_add_u32 {ka('pad')}, {ka('pad')}, 64")
         self.i(f"s_cmp_lg_u32 {S('qrem')}, 0")
         self.i(f"s_cbranch_scc1 {lq}")
         self.stamp(2, fine=True)
         self.i("s_waitcnt vmcnt(0)")
         self.stamp(9, fine=True)                # bucket 9: the wait for this wave's own DMA pieces
         self.lab(lb)
+        if self.kmask:
+            self.i(self.mask_word(p))           # tile j+2 -> MK((j+2) & 1) = MK(p)
         self.i("s_barrier")
         self.stamp(12, fine=True)               # bucket 12: the barrier
         self.out_of_line(True)
@@ -638,6 +691,7 @@ class Gen:
         pre, fin = fin[:npre], fin[npre:]
         lg = self.run_phase(self.phase_qk, fin, Lgkm(), p=p, dma_at=dma, pre=pre, tail_vreads=p)
         self.stamp(0, fine=True)
+        self.mask_keys(1 - p, 1 - p)           # tile j+1: buffer 1-p, word MK((j+1) & 1)
         if self.causal:                        # the diagonal tile of this wave is tile wnt-1 = j+1  <=>  wrem == 1
             lm, lr = self.ul("mask"), self.ul("masked")
             self.i(f"s_cmp_eq_u32 {S('wrem')}, 1")
@@ -876,6 +930,7 @@ class Gen:
         # QK^T(0) from K slot 0 into buffer 0; four O zeros per gap
         zero = [[f"v_accvgpr_write_b32 a{4 * hs + k}, 0" for k in range(4)] for hs in range(2 * self.NKF)]
         self.phase_qk(1, zero, {})            # parity argument 1: target buffer 0, K slot 0
+        self.mask_keys(0, 0)
         if self.causal:
             lm, lr = self.ul("mask0"), self.ul("masked0")
             self.i(f"s_cmp_eq_u32 {S('wrem')}, 0")          # wnt == 1: tile 0 is this wave's diagonal tile
@@ -1259,6 +1314,12 @@ class Gen:
         self.i(f"s_lshl_b32 {S('qdst')}, {S('w4k')}, 2")
         self.i(f"s_add_u32 {S('qdst')}, {S('qdst')}, {self.Q_BASE}")
         self.i(f"s_mov_b32 {S('qoff')}, 0")
+        if self.kmask:                         # mask bytes of tiles 0 and 1, ahead of every DMA piece (the counted wait below covers them)
+            self.i(f"s_mul_i32 {ka('pad')}, {S('n_b')}, {ka('Sk')}")
+            self.emit(self.mask_load(0))
+            self.i(f"s_add_u32 {ka('pad')}, {ka('pad')}, 64")
+            self.emit(self.mask_load(1))
+            self.i(f"s_add_u32 {ka('pad')}, {ka('pad')}, 64")                     # next: tile 2
         self.i(f"s_mov_b32 {S('qrem')}, {self.PPW}")
         for g in range(self.PPW):                # the wave's 64 rows, 4 KiB a group
             self.q_group()
@@ -1282,6 +1343,9 @@ class Gen:
         self.i(f"s_add_u32 {S('koff')}, {S('koff')}, {S('ktile')}")               # next K piece: tile 2
         self.i(f"s_add_u32 {S('voff')}, {S('voff')}, {S('vtile')}")               # next V piece: tile 1
         self.i(f"s_waitcnt vmcnt({2 * self.PPW})")                                # Q and K0 (the pieces of V0, K1 are the youngest)
+        if self.kmask:
+            self.i(self.mask_word(0, 0))
+            self.i(self.mask_word(1, 1))
         self.i("s_barrier")
         litem = f".L{n}_item"
         self.lab(litem)
@@ -1317,12 +1381,12 @@ class Gen:
         self.lab(lloop)
         for p in (0, 1):
             lnf, ll, ld = (self.ul(x) for x in ("notfull", "last", "done"))
-            self.stream_top()
+            self.stream_top(p)
             self.i(f"s_cmp_gt_i32 {S('wrem')}, 0")
             self.i(f"s_cbranch_scc0 {lnf}")
             self.body_full(p)
             self.lab(ld)
-            self.stream_bottom()
+            self.stream_bottom(p)
             self.out_of_line(True)
             self.lab(lnf)
             self.i(f"s_cmp_eq_u32 {S('wrem')}, 0")
@@ -1363,7 +1427,7 @@ class Gen:
 		.amdhsa_system_sgpr_workgroup_id_z 0
 		.amdhsa_system_vgpr_workitem_id 0
 		.amdhsa_next_free_vgpr 512
-		.amdhsa_next_free_sgpr {KBASE_SGPR + KARG_DWORDS}
+		.amdhsa_next_free_sgpr {KBASE_SGPR + KARG_DWORDS + 2}
 		.amdhsa_accum_offset 256
 		.amdhsa_reserve_vcc 1
 		.amdhsa_float_round_mode_32 0
@@ -1391,7 +1455,7 @@ class Gen:
     .max_flat_workgroup_size: 256
     .name:           {n}
     .private_segment_fixed_size: 0
-    .sgpr_count:     {KBASE_SGPR + KARG_DWORDS + 6}
+    .sgpr_count:     {KBASE_SGPR + KARG_DWORDS + 2 + 6}
     .sgpr_spill_count: 0
     .symbol:         {n}.kd
     .uniform_work_group_size: 1
@@ -1404,7 +1468,8 @@ class Gen:
 
 def kernels():
     """(dtype, causal, parity): parity = fp32 store + split P (the <= 1e-3 variant on the same schedule)"""
-    return [(dt, D, causal, par) for dt in ("bf16", "fp16") for D in (128, 64) for causal in (True, False) for par in (False, True)]
+    return [(dt, D, causal, km, par) for dt in ("bf16", "fp16") for D in (128, 64) for causal in (True, False)
+            for km in ((False,) if STAMP else (False, True)) for par in (False, True)]
 
 
 def main():
@@ -1417,8 +1482,8 @@ def main():
         return
     out = ['\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', "\t.amdhsa_code_object_version 6", "\t.text"]
     meta = []
-    for dt, D, causal, par in kernels():
-        g = Gen(dt, causal, out32=par, split=par, D=D)
+    for dt, D, causal, km, par in kernels():
+        g = Gen(dt, causal, out32=par, split=par, D=D, kmask=km)
         g.kernel()
         out += g.main
         out.append(g.descriptor())

@@ -89,8 +89,8 @@ Variant exp_variant(bool causal) {
 Variant p4_variant(const pfa_fa3_args* a, bool causal) {
     Variant v;
     v.fn = nullptr;
-    snprintf(v.name, sizeof(v.name), "fa3_fwd_p4_%s_d%d_%s_%s", a->dtype_in == PFA_DTYPE_BF16 ? "bf16" : "fp16", a->D, causal ? "causal" : "full",
-             a->dtype_out == PFA_DTYPE_FP32 ? "splitp_o32" : "o16");
+    snprintf(v.name, sizeof(v.name), "fa3_fwd_p4_%s_d%d_%s%s_%s", a->dtype_in == PFA_DTYPE_BF16 ? "bf16" : "fp16", a->D, causal ? "causal" : "full",
+             a->key_mask ? "_km" : "", a->dtype_out == PFA_DTYPE_FP32 ? "splitp_o32" : "o16");
     v.p4 = true;
     v.p4_grid = pfa::p4_workgroups(a);
     v.lds_bytes = 0;

@@ -56,7 +56,7 @@ namespace {
 constexpr int MAX_DEV = 64;
 struct DevMod {
     hipModule_t mod = nullptr;
-    hipFunction_t fn[2][2][2][2] = {};  // [dtype][D: 128, 64][causal][parity variant: fp32 store + split P]
+    hipFunction_t fn[2][2][2][2][2] = {};  // [dtype][D: 128, 64][causal][key mask][parity variant: fp32 store + split P]
     int n_cu = 0;
     int state = 0;                   // 0 = not tried, 1 = ready, -1 = failed
 };
@@ -88,11 +88,15 @@ const DevMod* module_for(int dev) {
         for (int d = 0; d < 2; ++d)
             for (int hd = 0; hd < 2; ++hd)
                 for (int c = 0; c < 2; ++c)
-                    for (int v = 0; v < 2; ++v) {
-                        char name[64];
-                        snprintf(name, sizeof(name), "fa3_fwd_p4_%s_d%d_%s_%s", dt[d], hd ? 64 : 128, cz[c], pv[v]);
-                        if (hipModuleGetFunction(&m.fn[d][hd][c][v], m.mod, name) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-                    }
+                    for (int km = 0; km < 2; ++km)
+                        for (int v = 0; v < 2; ++v) {
+                            char name[64];
+                            snprintf(name, sizeof(name), "fa3_fwd_p4_%s_d%d_%s%s_%s", dt[d], hd ? 64 : 128, cz[c], km ? "_km" : "", pv[v]);
+                            if (hipModuleGetFunction(&m.fn[d][hd][c][km][v], m.mod, name) != hipSuccess) {
+                                (void)hipGetLastError();
+                                return nullptr;
+                            }
+                        }
         m.state = 1;
     }
     return m.state == 1 ? &m : nullptr;
@@ -102,14 +106,16 @@ bool fits_u32(int64_t x) { return x >= 0 && x <= 0xffffffffLL; }
 }  // namespace
 
 // Shapes the persistent kernel takes (everything else stays on the HIP kernels): D = 128 or 64; the fast variant (one P operand, 16-bit
-// store) or the parity variant (split P AND fp32 store); no mask / seqlens, whole 256-row Q blocks and an even number of 64-key
+// store) or the parity variant (split P AND fp32 store); no element mask / seqlens (a [B, Sk] key mask with contiguous rows is read
+// by the kernel itself, 64 bytes per wave and tile: the *_km_* kernels), whole 256-row Q blocks and an even number of 64-key
 // tiles (the two S buffers alternate from tile 0 of every item), at least 4 tiles; under the causal mask Sq == Sk and an even
 // number of Q blocks (units are heavy + light block pairs).
 bool p4_eligible(const pfa_fa3_args* a) {
     const bool split = (a->flags & PFA_FLAG_SPLIT_P) != 0, out32 = a->dtype_out == PFA_DTYPE_FP32;
     if ((a->D != 128 && a->D != 64) || split != out32) return false;
     const int64_t osz = out32 ? 4 : 2;
-    if (a->key_mask || a->mask || a->seqlens_k) return false;
+    if (a->mask || a->seqlens_k) return false;
+    if (a->key_mask && (a->key_mask_stride_b != a->Sk || (int64_t)a->B * a->Sk > 0x7fffffffLL)) return false;   // its 32-bit running byte offset
     if (a->Sq % 256 != 0 || a->Sk % 128 != 0 || a->Sk < 256) return false;
     if (a->causal && (a->Sq != a->Sk || (a->Sq / 256) % 2 != 0)) return false;
     const int64_t st[] = {a->q_stride_b, a->q_stride_h, a->q_stride_s, a->k_stride_b, a->k_stride_h, a->k_stride_s,
@@ -164,10 +170,12 @@ int p4_launch(const pfa_fa3_args* a, void* stream, int* hip_err) {
     p.nt_full = (uint32_t)(a->Sk / 64);
     // diagnostic build only (P4_STAMP=1 make): per-wave cycle buckets go to the caller's workspace; the production kernel never reads it
     p.dbg = (a->workspace && a->workspace_bytes >= (size_t)grid * 4 * 16 * 4) ? (unsigned long long*)a->workspace : nullptr;
+    // key-mask kernels: the same kernarg slot carries the mask bytes, `pad` is the kernel's running byte offset into them
+    if (a->key_mask) p.dbg = (unsigned long long*)a->key_mask;
 
     size_t sz = sizeof(p);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-    hipFunction_t fn = m->fn[a->dtype_in == PFA_DTYPE_BF16 ? 0 : 1][a->D == 64 ? 1 : 0][a->causal ? 1 : 0][parity ? 1 : 0];
+    hipFunction_t fn = m->fn[a->dtype_in == PFA_DTYPE_BF16 ? 0 : 1][a->D == 64 ? 1 : 0][a->causal ? 1 : 0][a->key_mask ? 1 : 0][parity ? 1 : 0];
     int prev = -1;
     hipError_t e = hipGetDevice(&prev);
     if (e == hipSuccess && prev != a->device_id) e = hipSetDevice(a->device_id);

@@ -426,6 +426,55 @@ def test_p4_kernel_against_the_oracle_and_the_8_wave_kernel(case, dtype):
     assert err <= PARITY_TOL and float((p45 - p44).abs().max()) <= 3e-5, (case, dtype, err)
 
 
+@pytest.mark.parametrize("case", [(2, 8, 512, 512, True, 128), (3, 4, 256, 384, False, 128), (2, 4, 1024, 768, False, 64), (2, 8, 1024, 1024, True, 64)])
+@pytest.mark.parametrize("kind", ["padding", "random", "empty_row"])
+def test_p4_key_mask_kernels_against_the_oracle(case, kind):
+    """[B, Sk] key masks on the persistent schedule (fa3_fwd_p4_*_km_*: the waves read the mask bytes themselves): a visible prefix
+    per batch, random bytes (every tile takes the bit-test path), and a batch without any visible key (output 0, LSE -inf)."""
+    from oracle import fa3_oracle as orc
+    from photonic_flash_attention_amd import _capi, ops, synth
+    B, H, Sq, Sk, causal, D = case
+    q, k, v = synth.qkv(B, H, Sq, Sk, D, 4700 + Sq + D, "bf16")
+    g = torch.Generator().manual_seed(17 + Sq)
+    if kind == "padding":
+        lens = torch.randint(1, Sk + 1, (B,), generator=g)
+        lens[0] = Sk
+        km = torch.arange(Sk)[None, :] < lens[:, None]
+    else:
+        km = torch.rand(B, Sk, generator=g) < 0.7
+        if kind == "empty_row":
+            km[B - 1] = False
+    if causal:
+        km[:B - 1 if kind == "empty_row" else B, 0] = True                  # (row 0 sees only key 0)
+    qd, kd, vd = (t.to("cuda:0").permute(0, 2, 1, 3) for t in (q, k, v))
+    kmd = km.to("cuda:0")
+    o16, lse = ops.fa3_forward(qd, kd, vd, causal=causal, key_mask=kmd, return_lse=True)
+    o32, _ = ops.fa3_forward(qd, kd, vd, causal=causal, key_mask=kmd, out_dtype=torch.float32)
+    o44, l44 = ops.fa3_forward(qd, kd, vd, causal=causal, key_mask=kmd, out_dtype=torch.float32, return_lse=True, _variant=44)
+    torch.cuda.synchronize()
+    name = _capi.describe(ops.build_args(qd, kd, vd, o16, causal=causal, key_mask=kmd)[0])[0]
+    small = D == 64 and B * H * (Sq // 256) // (2 if causal else 1) > 256
+    assert small or name.startswith(f"fa3_fwd_p4_bf16_d{D}_{'causal' if causal else 'full'}_km_o16"), name      # picked without a selector
+    mask4 = km.view(B, 1, 1, Sk).expand(B, 1, Sq, Sk)
+    if causal:
+        mask4 = mask4 & orc.causal_mask(Sq, Sk)
+    dead = ~mask4.any(dim=-1)                                                # [B,1,Sq]: rows without a visible key
+    ref = orc.flash_attention_forward(q.float().permute(0, 2, 1, 3), k.float().permute(0, 2, 1, 3), v.float().permute(0, 2, 1, 3),
+                                      mask4).permute(0, 2, 1, 3)
+    ref = torch.where(dead.permute(0, 2, 1).unsqueeze(-1).expand_as(ref), torch.zeros_like(ref), ref)   # the kernels' convention for such rows
+    err = float((o32.permute(0, 2, 1, 3).cpu() - ref).abs().max())
+    assert err <= PARITY_TOL, (case, kind, err)
+    assert float((o32 - o44).abs().max()) <= 3e-5
+    assert float((o16.float() - o32).abs().max()) <= 2e-2
+    deadh = dead.expand(B, H, Sq).to("cuda:0")
+    assert bool((torch.isinf(lse) == deadh).all()) and float((lse - l44)[~deadh].abs().max()) <= 2e-5
+    assert float(o16.float()[deadh].abs().max() if bool(deadh.any()) else 0.0) == 0.0
+    # a mask whose rows are not contiguous stays on the HIP kernels
+    a, _keep = ops.build_args(qd, kd, vd, o16, causal=causal, key_mask=kmd)
+    a.key_mask_stride_b = Sk + 64
+    assert "p4" not in _capi.describe(a)[0]
+
+
 def test_p4_kernel_reads_fused_qkv_views_and_is_the_default_for_long_aligned_problems():
     from oracle import fa3_oracle as orc
     from photonic_flash_attention_amd import _capi, ops, synth
