@@ -88,6 +88,7 @@ def PDL(X, i):              # split P: the low halves (the VGPRs the 4-deep frag
 
 
 PKADD = int(os.environ.get("P4_PKADD", "0"))        # EXPERIMENT, off: row sums as v_pk_add_f32 on register pairs (32 instead of 64 instructions a tile) ran 5-7 % SLOWER
+LEAN = int(os.environ.get("P4_LEAN", "1"))          # the tile loop's lean path (kernel()): 0 = every iteration carries the full bookkeeping
 RING = int(os.environ.get("P4_RING", "8"))          # K / V^T fragment rings: 4 (VGPRs) or 8 (the spare accumulator registers a[192:255])
 KFR = lambda i: (192 + 4 * (i % 8)) if RING == 8 else (176 + 4 * (i % 4))
 VFR = lambda i: (224 + 4 * (i % 8)) if RING == 8 else (192 + 4 * (i % 4))
@@ -675,8 +676,9 @@ class Gen:
             out.append(take)
         return out, st
 
-    def body_full(self, p):
-        self.cm(f"FULL body, parity {p}: QK^T(j+1) || softmax finish(j);  PV(j) || softmax start(j+1)")
+    def body_full(self, p, lean=False):
+        """lean: an iteration the caller knows to be far from the item's ends (no diagonal tile, see the loop in kernel())"""
+        self.cm(f"FULL body, parity {p}{' (lean loop)' if lean else ''}: QK^T(j+1) || softmax finish(j);  PV(j) || softmax start(j+1)")
         self.stamp(2)
         self.abl_on = True
         # ---- phase A: the finish of both strips as ONE in-order stream, sliced evenly over the gaps around their fixed content
@@ -692,7 +694,7 @@ class Gen:
         lg = self.run_phase(self.phase_qk, fin, Lgkm(), p=p, dma_at=dma, pre=pre, tail_vreads=p)
         self.stamp(0, fine=True)
         self.mask_keys(1 - p, 1 - p)           # tile j+1: buffer 1-p, word MK((j+1) & 1)
-        if self.causal:                        # the diagonal tile of this wave is tile wnt-1 = j+1  <=>  wrem == 1
+        if self.causal and not lean:           # the diagonal tile of this wave is tile wnt-1 = j+1  <=>  wrem == 1
             lm, lr = self.ul("mask"), self.ul("masked")
             self.i(f"s_cmp_eq_u32 {S('wrem')}, 1")
             self.i(f"s_cbranch_scc1 {lm}")
@@ -1377,8 +1379,33 @@ class Gen:
         self.i("s_barrier")                    # V0 / K1 published; every wave is done with K slot 0
         self.stamp(3, count=8)
         # ---- tile loop, unrolled by the two S buffers ----------------------------------------------------------------------------------
-        lloop = f".L{n}_loop"
+        lloop, lgen = f".L{n}_loop", f".L{n}_generic"
         self.lab(lloop)
+        if LEAN and not STAMP:
+            # Two tiles at a time WITHOUT the per-iteration bookkeeping, while this wave is far from both ends of the item: no Q
+            # pieces left to request (qrem == 0), no stream switch in either iteration (krem >= 2) and, under the causal mask, FULL
+            # bodies without a diagonal tile (wrem = krem - 2 + wave >= 3).  A lean iteration issues the same DMA pieces and meets the
+            # same barriers as a generic one, so every wave decides for itself.  (17 scalar instructions a tile were ~9 % of it.)
+            self.i(f"s_cmp_lt_u32 {S('krem')}, {5 if self.causal else 2}")
+            self.i(f"s_cbranch_scc1 {lgen}")
+            self.i(f"s_cmp_lg_u32 {S('qrem')}, 0")
+            self.i(f"s_cbranch_scc1 {lgen}")
+            for p in (0, 1):
+                if self.kmask:
+                    self.emit(self.mask_load())
+                self.body_full(p, lean=True)
+                self.i(f"s_add_u32 {S('koff')}, {S('koff')}, {S('ktile')}")
+                self.i(f"s_add_u32 {S('voff')}, {S('voff')}, {S('vtile')}")
+                if self.kmask:
+                    self.i(f"s_add_u32 {ka('pad')}, {ka('pad')}, 64")
+                self.i("s_waitcnt vmcnt(0)")
+                if self.kmask:
+                    self.i(self.mask_word(p))
+                self.i("s_barrier")
+            for c in ("krem", "vrem", "wrem", "irem"):
+                self.i(f"s_sub_u32 {S(c)}, {S(c)}, 2")
+            self.i(f"s_branch {lloop}")
+            self.lab(lgen)
         for p in (0, 1):
             lnf, ll, ld = (self.ul(x) for x in ("notfull", "last", "done"))
             self.stream_top(p)
