@@ -581,7 +581,7 @@ class Gen:
         self.lab(l2)
 
     def stream_bottom(self, p):
-        """Q pieces of the next item (first four iterations of an item), the counted wait, the barrier."""
+        """Q pieces of the next item (first two iterations of an item; one at D = 64), the counted wait, the barrier."""
         lq, lb = self.ul("q"), self.ul("bar")
         self.i(f"s_add_u32 {S('koff')}, {S('koff')}, {S('ktile')}")
         self.i(f"s_add_u32 {S('voff')}, {S('voff')}, {S('vtile')}")
@@ -603,7 +603,8 @@ class Gen:
         self.out_of_line(True)
         self.lab(lq)
         self.q_group()
-        self.i("s_waitcnt vmcnt(4)")            # everything but the four Q pieces just issued
+        self.q_group()                          # two groups an iteration: the next item's Q block is complete by the third iteration
+        self.i("s_waitcnt vmcnt(8)")            # everything but the eight Q pieces just issued
         self.i(f"s_branch {lb}")
         self.out_of_line(False)
 
@@ -889,6 +890,15 @@ class Gen:
         self.i(f"s_addc_u32 {S('lsrd', 1)}, {ka('lse', hi=True)}, {th}")
         self.i(f"s_and_b32 {S('lsrd', 1)}, {S('lsrd', 1)}, 0xffff")
 
+    def zero_o(self):
+        """O = 0 on the matrix pipe: one MFMA of zero operands per 16 accumulator registers (8 instructions instead of 128 writes)."""
+        z = V_T[0]
+        for k in range(4):
+            self.i(f"v_mov_b32 {vr(z + k)}, 0")
+        self.i("s_nop 3")                     # VALU write -> MFMA operand read
+        for b0 in range(0, 2 * 16 * self.DB, 16):
+            self.i(f"{self.mf} {ar(b0, 16)}, {vr(z, 4)}, {vr(z, 4)}, 0")
+
     # ---- per-item prologue and epilogue ------------------------------------------------------------------------------------------
     def item_prologue(self):
         """Q fragments out of the landing zone into the accumulator file, state, QK^T(0) (O zeroed in its shadow), softmax start(0)."""
@@ -930,8 +940,8 @@ class Gen:
                 self.i(f"v_mov_b32 {vr(PSP(X) + 1)}, 0")
         self.i("s_waitcnt lgkmcnt(0)")
         # QK^T(0) from K slot 0 into buffer 0; four O zeros per gap
-        zero = [[f"v_accvgpr_write_b32 a{4 * hs + k}, 0" for k in range(4)] for hs in range(2 * self.NKF)]
-        self.phase_qk(1, zero, {})            # parity argument 1: target buffer 0, K slot 0
+        self.zero_o()
+        self.phase_qk(1, [[] for _ in range(2 * self.NKF)], {})       # parity argument 1: target buffer 0, K slot 0
         self.mask_keys(0, 0)
         if self.causal:
             lm, lr = self.ul("mask0"), self.ul("masked0")
@@ -1055,7 +1065,7 @@ class Gen:
             self.lab(ll)
             self.i("s_waitcnt lgkmcnt(0)")
             NI = 32 // RPI
-            x = [16 + 4 * k for k in range(NI)]                 # S buffer 0 is dead here: the 16-byte read-back registers
+            x = [84 + 4 * k for k in range(NI)]                 # S buffer 1 is dead here (an item's last tile is odd): the 16-byte read-back registers
             for k in range(NI):
                 self.i(f"ds_read_b128 {vr(x[k], 4)}, {vr(rb[k & 3])} offset:{(k >> 2) * 4096}")
             if X == 'A':
