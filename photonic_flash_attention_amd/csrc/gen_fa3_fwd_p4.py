@@ -88,6 +88,7 @@ def PDL(X, i):              # split P: the low halves (the VGPRs the 4-deep frag
 
 
 PKADD = int(os.environ.get("P4_PKADD", "0"))        # EXPERIMENT, off: row sums as v_pk_add_f32 on register pairs (32 instead of 64 instructions a tile) ran 5-7 % SLOWER
+SEAM = int(os.environ.get("P4_SEAM", "1"))          # the item seam as one more FULL iteration (kernel(), body_seam): 0 = LAST body, epilogue, prologue one after the other
 LEAN = int(os.environ.get("P4_LEAN", "1"))          # the tile loop's lean path (kernel()): 0 = every iteration carries the full bookkeeping
 RING = int(os.environ.get("P4_RING", "8"))          # K / V^T fragment rings: 4 (VGPRs) or 8 (the spare accumulator registers a[192:255])
 KFR = lambda i: (192 + 4 * (i % 8)) if RING == 8 else (176 + 4 * (i % 4))
@@ -102,6 +103,10 @@ ST = {"m": 0, "l": 1, "mc": 2, "thr": 3, "al": 4, "ps0": 5}
 
 def STV(X, f):
     return 236 + (0 if X == 'A' else 6) + ST[f]
+
+
+def SV(X, f):               # row sum / scaled max of the item that is ending, parked in S buffer 1 across the pipelined seam (body_seam)
+    return 80 + (0 if X == 'A' else 2) + (0 if f == 'l' else 1)
 
 
 def PSP(X):                 # packed row-sum accumulator of a strip (two lanes of a v_pk_add_f32): v[176:177] / v[178:179]
@@ -281,7 +286,7 @@ class Gen:
     # reads the 64 bytes of a tile itself (lane i: key 64 t + i, one global_load_ubyte) two tiles ahead, beside the K pieces of that
     # tile and with the same stream switch; at the bottom of the iteration (behind its counted vmcnt) a compare turns them into the
     # 64-bit word MK(t & 1): bit i = key 64 t + i visible.  `pad` = the running byte offset b * Sk + 64 t.
-    KM_V = [V_E[4], V_E[5]]                    # the bytes in flight (scratch registers nothing else touches inside the tile loop)
+    KM_V = [V_E[14], V_E[15]]                  # the bytes in flight (scratch registers nothing else touches inside the tile loop)
 
     @staticmethod
     def MK(i):
@@ -900,14 +905,12 @@ class Gen:
             self.i(f"{self.mf} {ar(b0, 16)}, {vr(z, 4)}, {vr(z, 4)}, 0")
 
     # ---- per-item prologue and epilogue ------------------------------------------------------------------------------------------
-    def item_prologue(self):
-        """Q fragments out of the landing zone into the accumulator file, state, QK^T(0) (O zeroed in its shadow), softmax start(0)."""
-        self.cm("item prologue")
-        # this item's Q pieces: everything but the previous item's output stores (issued after them: 16, or 32 of the fp32 epilogue)
-        self.i(f"s_waitcnt vmcnt({(8 if self.out32 else 4) * self.DB})")
-        qb = V_E[0:8]        # per-lane addresses of the Q fragments (recomputed per item: nothing lane-constant is kept live for it)
+    def q_fragments(self, lg=None):
+        """This wave's 64 rows out of its landing zone into the accumulator file (per-lane addresses recomputed per item: nothing
+        lane-constant is kept live for it); lg: the LDS-read tracker of the phase that follows."""
+        qb = V_E[0:8]
         T0, T1, T2 = (vr(x) for x in V_T[0:3])
-        # address = qland + r * 256 + (((2 ks + h) ^ (r & 15)) << 4)  =  rowbase ^ (32 ks),  qland = Q_BASE + wave * 16384
+        # address = qland + r * 256 + (((2 ks + h) ^ (r & 15)) << 4)  =  rowbase ^ (32 ks),  qland = Q_BASE + wave * TILE
         self.i(f"s_lshl_b32 {S('t0')}, {S('w4k')}, 2")
         self.i(f"s_add_u32 {S('t0')}, {S('t0')}, {self.Q_BASE}")
         if self.D == 128:
@@ -926,33 +929,102 @@ class Gen:
         for X, off in (('A', 0), ('B', self.HALF)):
             for ks in range(self.KS):
                 self.i(f"ds_read_b128 {ar(self.QA(X, ks), 4)}, {vr(qb[ks])} offset:{off}")
+                if lg is not None:
+                    lg.issue(('q', X, ks))
+
+    def state_reset(self, emit=True):
+        o = []
         for X in "AB":
-            self.i(f"v_mov_b32 {vr(STV(X, 'm'))}, {NEG_BIG}")
-            self.i(f"v_mov_b32 {vr(STV(X, 'thr'))}, {NEG_BIG}")
-            self.i(f"v_mul_f32 {vr(STV(X, 'mc'))}, {ka('scale_log2')}, {vr(STV(X, 'm'))}")
-            self.i(f"v_mov_b32 {vr(STV(X, 'l'))}, 0")
-            self.i(f"v_mov_b32 {vr(STV(X, 'ps0'))}, 0")
-            self.i(f"v_mov_b32 {vr(STV(X, 'al'))}, 1.0")
-        self.i(f"v_mov_b32 {vr(V_PS1)}, 0")
+            o += [f"v_mov_b32 {vr(STV(X, 'm'))}, {NEG_BIG}",
+                  f"v_mov_b32 {vr(STV(X, 'thr'))}, {NEG_BIG}",
+                  f"v_mul_f32 {vr(STV(X, 'mc'))}, {ka('scale_log2')}, {vr(STV(X, 'm'))}",
+                  f"v_mov_b32 {vr(STV(X, 'l'))}, 0",
+                  f"v_mov_b32 {vr(STV(X, 'ps0'))}, 0",
+                  f"v_mov_b32 {vr(STV(X, 'al'))}, 1.0"]
+        o.append(f"v_mov_b32 {vr(V_PS1)}, 0")
         if PKADD and not self.split:
             for X in "AB":
-                self.i(f"v_mov_b32 {vr(PSP(X))}, 0")
-                self.i(f"v_mov_b32 {vr(PSP(X) + 1)}, 0")
+                o += [f"v_mov_b32 {vr(PSP(X))}, 0", f"v_mov_b32 {vr(PSP(X) + 1)}, 0"]
+        if emit:
+            self.emit(o)
+        return o
+
+    def tile0_diag(self, cond):
+        """Causal: tile 0 is this wave's diagonal tile when its tile count is 1; `cond` = instructions that leave SCC = 1 in that case."""
+        if not self.causal:
+            return
+        lm, lr = self.ul("mask0"), self.ul("masked0")
+        self.emit(cond)
+        self.i(f"s_cbranch_scc1 {lm}")
+        self.lab(lr)
+        self.out_of_line(True)
+        self.lab(lm)
+        self.mask_diag(0)
+        self.i(f"s_branch {lr}")
+        self.out_of_line(False)
+
+    def body_seam(self, full):
+        """The last iteration of an item that has a successor, parity 1: the K/V stream already delivers the successor's tiles 0 / 1
+        and its Q rows landed iterations ago, so this IS a FULL iteration once the Q fragments are swapped -- QK^T_next(0) beside
+        finish(j), PV(j) beside start_next(0) -- instead of a LAST body, an epilogue and a prologue with nothing to overlap.  The
+        ending item's row sums / maxima move to SV() for its epilogue, which follows; O is zeroed after that (zero_o).
+        full: this wave's last tile is j (else it is past its last tile: only the successor's half of the work)."""
+        p = 1
+        self.cm(f"SEAM body ({'last tile' if full else 'past the last tile'}): QK^T_next(0) || finish(j);  PV(j) || start_next(0)")
+        park = []
+        for X in "AB":
+            park += [f"v_mov_b32 {vr(SV(X, 'l'))}, {vr(STV(X, 'l'))}", f"v_mov_b32 {vr(SV(X, 'mc'))}, {vr(STV(X, 'mc'))}"]
+        park += self.state_reset(emit=False)
+        sta = self.start_stream('A', 0) + self.start_stream('B', 0)
+        unit = [f"v_mov_b32 {vr(STV(X, 'al'))}, 1.0" for X in "AB"]
+        # tile 0 of the successor is this wave's diagonal tile iff its tile count is 1: nt_n - 3 + wave == 1
+        cond = [f"s_add_u32 {S('t0')}, {S('nt_n')}, {S('wave')}", f"s_cmp_eq_u32 {S('t0')}, 4"]
+        lg = Lgkm()
+        if full:
+            self.abl_on = True
+            self.q_fragments(lg)
+            fin = self.finish_stream('A', p) + self.finish_stream('B', p)
+            n = 2 * self.NKF
+            gv = [g * n // 32 for g in DMA_GAPS_V][:self.PPW] if self.PPW == 4 else [1 * n // 16, 5 * n // 16]
+            gk = [g * n // 32 for g in DMA_GAPS_K][:self.PPW] if self.PPW == 4 else [9 * n // 16, 13 * n // 16]
+            dma = self.dma_plan(p, gv, gk)
+            lg = self.run_phase(self.phase_qk, fin, lg, p=p, dma_at=dma, tail_vreads=p)
+            self.mask_keys(0, 0)
+            self.tile0_diag(cond)
+            self.run_phase(self.phase_pv, park + sta + unit, lg, p=p, dma_at={}, preissued=True)
+            self.abl_on = False
+        else:
+            self.i(self.setm0('v', 1 - p))
+            self.i("s_nop 0")
+            for t in range(self.PPW):
+                self.i(self.dma('V', t))
+            self.i(self.setm0('k', p))
+            self.i("s_nop 0")
+            for t in range(self.PPW):
+                self.i(self.dma('K', t))
+            self.q_fragments(lg)
+            self.emit(park)
+            self.phase_qk(p, [[] for _ in range(2 * self.NKF)], {}, lg=lg)
+            self.mask_keys(0, 0)
+            self.tile0_diag(cond)
+            self.i("s_nop 7")
+            self.i("s_nop 7")
+            self.emit(sta + unit)
+        self.i(f"s_mov_b64 {S('grow')}, 0")
+
+    def item_prologue(self):
+        """Q fragments out of the landing zone into the accumulator file, state, QK^T(0) (O zeroed in its shadow), softmax start(0)."""
+        self.cm("item prologue")
+        # this item's Q pieces: everything but the previous item's output stores (issued after them: 16, or 32 of the fp32 epilogue)
+        self.i(f"s_waitcnt vmcnt({(8 if self.out32 else 4) * self.DB})")
+        self.q_fragments()
+        self.state_reset()
         self.i("s_waitcnt lgkmcnt(0)")
         # QK^T(0) from K slot 0 into buffer 0; four O zeros per gap
         self.zero_o()
         self.phase_qk(1, [[] for _ in range(2 * self.NKF)], {})       # parity argument 1: target buffer 0, K slot 0
         self.mask_keys(0, 0)
-        if self.causal:
-            lm, lr = self.ul("mask0"), self.ul("masked0")
-            self.i(f"s_cmp_eq_u32 {S('wrem')}, 0")          # wnt == 1: tile 0 is this wave's diagonal tile
-            self.i(f"s_cbranch_scc1 {lm}")
-            self.lab(lr)
-            self.out_of_line(True)
-            self.lab(lm)
-            self.mask_diag(0)
-            self.i(f"s_branch {lr}")
-            self.out_of_line(False)
+        self.tile0_diag([f"s_cmp_eq_u32 {S('wrem')}, 0"])          # wnt == 1
         self.i("s_nop 7")
         self.i("s_nop 7")
         for X in "AB":
@@ -961,13 +1033,16 @@ class Gen:
             self.i(f"v_mov_b32 {vr(STV(X, 'al'))}, 1.0")
         self.i(f"s_mov_b64 {S('grow')}, 0")
 
-    def item_epilogue(self):
-        """Normalise, convert, stage the strip as a [32 rows][256 B] image in the wave's own LDS, store whole rows; LSE."""
-        self.cm("item epilogue")
+    def item_epilogue(self, saved=False):
+        """Normalise, convert, stage the strip as a [32 rows][256 B] image in the wave's own LDS, store whole rows; LSE.
+        saved: behind a pipelined seam (body_seam) -- the item's row sums / maxima are in SV(), S buffer 0 and the softmax state already
+        belong to the next item."""
+        self.cm("item epilogue" + (" (behind a pipelined seam)" if saved else ""))
         self.i("s_nop 15")
         self.i("s_nop 15")                    # last MFMA -> v_accvgpr_read
+        ST_ = SV if saved else STV
         if self.out32:
-            return self.item_epilogue_f32()
+            return self.item_epilogue_f32(ST_)
         vb, rb = V_E[8], V_E[9:13]            # staging write base, read-back bases
         inv, lt, t = V_E[13], V_E[14], V_E[15]
         L, T0, T1, T2, T3 = vr(V_LANE), *(vr(x) for x in V_T)
@@ -1024,7 +1099,7 @@ class Gen:
         RPI = 1024 // self.RB                                                     # rows one store instruction covers
         self.i(f"s_lshl_b32 {S('t1')}, {ka('o_ss')}, {2 if RPI == 4 else 3}")
         for X in "AB":
-            l, mc = vr(STV(X, 'l')), vr(STV(X, 'mc'))
+            l, mc = vr(ST_(X, 'l')), vr(ST_(X, 'mc'))
             self.i(f"v_mov_b32 {vr(t)}, {l}")
             self.i("s_nop 1")
             self.i(f"v_permlane32_swap_b32 {l}, {vr(t)}")
@@ -1079,7 +1154,7 @@ class Gen:
                     self.i(f"s_add_u32 {S('t0')}, {S('t0')}, {S('t1')}")
         self.i(f"v_mov_b32 {vr(V_PS1)}, 0")
 
-    def item_epilogue_f32(self):
+    def item_epilogue_f32(self, ST_=STV):
         """Parity variant: normalise and store fp32 straight from the accumulators (a lane holds 4 consecutive columns of its row per
         register quad: one 16-byte store each); LSE as in the 16-bit epilogue."""
         inv, lt, t = V_E[13], V_E[14], V_E[15]
@@ -1095,7 +1170,7 @@ class Gen:
         self.i(f"s_lshl_b32 {S('t1')}, {S('wave')}, 6")                             # 64 wave
         self.i(f"s_mul_i32 {S('t1')}, {S('t1')}, {ka('o_ss')}")                     # the wave's first output row
         for X in "AB":
-            l, mc = vr(STV(X, 'l')), vr(STV(X, 'mc'))
+            l, mc = vr(ST_(X, 'l')), vr(ST_(X, 'mc'))
             self.i(f"v_mov_b32 {vr(t)}, {l}")
             self.i("s_nop 1")
             self.i(f"v_permlane32_swap_b32 {l}, {vr(t)}")
@@ -1269,6 +1344,31 @@ class Gen:
             self.i(f"v_add_u32 {e4}, {e4}, {e2}")
             self.i(f"v_subrev_u32 {vr(QDOFF(t))}, {1024 * t}, {e4}")
 
+    def item_switch(self):
+        # ---- item switch: the decoded item becomes current; decode the one after it ----------------------------------------------------
+        self.i(f"s_mov_b32 {S('irem')}, {S('n_nt')}")
+        self.i(f"s_sub_u32 {S('krem')}, {S('n_nt')}, 2")
+        self.i(f"s_sub_u32 {S('vrem')}, {S('n_nt')}, 1")
+        if self.causal:
+            self.i(f"s_add_u32 {S('wrem')}, {S('n_nt')}, {S('wave')}")
+            self.i(f"s_sub_u32 {S('wrem')}, {S('wrem')}, 4")                      # wnt - 1 = nt - 4 + wave
+        else:
+            self.i(f"s_sub_u32 {S('wrem')}, {S('n_nt')}, 1")
+        self.make_out_srds()
+        if self.causal:
+            self.i(f"s_xor_b32 {S('n_sub')}, {S('n_sub')}, 1")
+            self.i(f"s_cmp_eq_u32 {S('n_sub')}, 0")
+            self.i(f"s_cselect_b32 {S('t0')}, 1, 0")
+            self.i(f"s_add_u32 {S('n_u')}, {S('n_u')}, {S('t0')}")
+        else:
+            self.i(f"s_add_u32 {S('n_u')}, {S('n_u')}, 1")
+        self.decode()
+        self.i(f"s_mov_b32 {S('nt_n')}, {S('n_nt')}")
+        self.i(f"s_lshl_b32 {S('qrem')}, {S('n_valid')}, {2 if self.PPW == 4 else 1}")   # PPW groups of Q pieces if there is a next item
+        self.i(f"s_lshl_b32 {S('qdst')}, {S('w4k')}, 2")
+        self.i(f"s_add_u32 {S('qdst')}, {S('qdst')}, {self.Q_BASE}")
+        self.i(f"s_mov_b32 {S('qoff')}, 0")
+
     # ---- the kernel --------------------------------------------------------------------------------------------------------------
     def kernel(self):
         n = self.name
@@ -1361,29 +1461,7 @@ class Gen:
         self.i("s_barrier")
         litem = f".L{n}_item"
         self.lab(litem)
-        # ---- item switch: the decoded item becomes current; decode the one after it ----------------------------------------------------
-        self.i(f"s_mov_b32 {S('irem')}, {S('n_nt')}")
-        self.i(f"s_sub_u32 {S('krem')}, {S('n_nt')}, 2")
-        self.i(f"s_sub_u32 {S('vrem')}, {S('n_nt')}, 1")
-        if self.causal:
-            self.i(f"s_add_u32 {S('wrem')}, {S('n_nt')}, {W}")
-            self.i(f"s_sub_u32 {S('wrem')}, {S('wrem')}, 4")                      # wnt - 1 = nt - 4 + wave
-        else:
-            self.i(f"s_sub_u32 {S('wrem')}, {S('n_nt')}, 1")
-        self.make_out_srds()
-        if self.causal:
-            self.i(f"s_xor_b32 {S('n_sub')}, {S('n_sub')}, 1")
-            self.i(f"s_cmp_eq_u32 {S('n_sub')}, 0")
-            self.i(f"s_cselect_b32 {S('t0')}, 1, 0")
-            self.i(f"s_add_u32 {S('n_u')}, {S('n_u')}, {S('t0')}")
-        else:
-            self.i(f"s_add_u32 {S('n_u')}, {S('n_u')}, 1")
-        self.decode()
-        self.i(f"s_mov_b32 {S('nt_n')}, {S('n_nt')}")
-        self.i(f"s_lshl_b32 {S('qrem')}, {S('n_valid')}, {2 if self.PPW == 4 else 1}")   # PPW groups of Q pieces if there is a next item
-        self.i(f"s_lshl_b32 {S('qdst')}, {S('w4k')}, 2")
-        self.i(f"s_add_u32 {S('qdst')}, {S('qdst')}, {self.Q_BASE}")
-        self.i(f"s_mov_b32 {S('qoff')}, 0")
+        self.item_switch()
         self.item_prologue()
         self.i("s_waitcnt vmcnt(0)")
         self.i("s_barrier")                    # V0 / K1 published; every wave is done with K slot 0
@@ -1416,8 +1494,17 @@ class Gen:
                 self.i(f"s_sub_u32 {S(c)}, {S(c)}, 2")
             self.i(f"s_branch {lloop}")
             self.lab(lgen)
+        use_seam = SEAM and not STAMP
+        lseam = f".L{n}_seam"
         for p in (0, 1):
             lnf, ll, ld = (self.ul(x) for x in ("notfull", "last", "done"))
+            if p == 1 and use_seam:           # the item's last iteration, and another item follows: the pipelined seam (below)
+                lnorm = self.ul("noseam")
+                self.i(f"s_cmp_eq_u32 {S('irem')}, 2")
+                self.i(f"s_cbranch_scc0 {lnorm}")
+                self.i(f"s_cmp_lg_u32 {S('n_valid')}, 0")
+                self.i(f"s_cbranch_scc1 {lseam}")
+                self.lab(lnorm)
             self.stream_top(p)
             self.i(f"s_cmp_gt_i32 {S('wrem')}, 0")
             self.i(f"s_cbranch_scc0 {lnf}")
@@ -1445,6 +1532,23 @@ class Gen:
         self.stamp_dump()
         self.lab(lend)
         self.i("s_endpgm")
+        if use_seam:
+            # ---- the pipelined seam: last iteration of an item with a successor, the ending item's epilogue, O = 0, item switch ----------
+            lsk, lsd = self.ul("seamskip"), self.ul("seamdone")
+            self.lab(lseam)
+            self.stream_top(1)
+            self.i(f"s_cmp_eq_u32 {S('wrem')}, 0")
+            self.i(f"s_cbranch_scc0 {lsk}")
+            self.body_seam(True)
+            self.i(f"s_branch {lsd}")
+            self.lab(lsk)
+            self.body_seam(False)
+            self.lab(lsd)
+            self.stream_bottom(1)
+            self.item_epilogue(saved=True)
+            self.zero_o()
+            self.item_switch()
+            self.i(f"s_branch {lloop}")
         self.main += self.ool
         self.main += [f".L{n}_fend:", f"\t.size\t{n}, .L{n}_fend-{n}"]
 
