@@ -120,7 +120,7 @@ V_TA = 254            # causal: r + 1 - 4h (element-mask threshold of the diagon
 V_LANE = 255
 V_E = list(range(0, 16))   # prologue / epilogue / rescale scratch (v0 = workitem id at entry)
 import os
-STAMP = int(os.environ.get("P4_STAMP", "0"))      # 1: every phase; 2: one stamp per iteration only (buckets 0 / 1 stay empty)
+STAMP = int(os.environ.get("P4_STAMP", "0"))      # 1: every phase; 2: one stamp per iteration only (buckets 0 / 1 stay empty); 3: kernel totals only (lean loop and pipelined seam stay on)
 ABL = os.environ.get("P4_ABL", "")                                         # timing-only ablations, see dma_plan
 DMA_PRICE = int(os.environ.get("P4_DMA_PRICE", "30"))                      # issue cycles budgeted for one LDS-DMA piece
 DMA_GAPS_V = [int(x) for x in os.environ.get("P4_DMA_GAPS_V", "1,5,9,13").split(",")]      # QK^T gaps that carry the V(j+1) pieces
@@ -228,7 +228,7 @@ class Gen:
     # a192 = previous s_memtime (low word), a[193 + k] = cycles accumulated in bucket k: 0 QK^T phase, 1 PV phase, 2 wait + barrier +
     # stream bookkeeping, 3 item switch + prologue, 4 epilogue, 5 LAST bodies, 6 SKIP bodies, 7 FULL iterations (count), 8 items (count)
     def stamp(self, k, count=None, fine=False):
-        if not STAMP or (fine and STAMP == 2):
+        if not STAMP or STAMP == 3 or (fine and STAMP == 2):
             return
         assert RING == 8, "stamps live in the VGPRs the 4-deep rings use"
         if self.split:
@@ -1469,7 +1469,7 @@ class Gen:
         # ---- tile loop, unrolled by the two S buffers ----------------------------------------------------------------------------------
         lloop, lgen = f".L{n}_loop", f".L{n}_generic"
         self.lab(lloop)
-        if LEAN and not STAMP:
+        if LEAN and STAMP in (0, 3):
             # Two tiles at a time WITHOUT the per-iteration bookkeeping, while this wave is far from both ends of the item: no Q
             # pieces left to request (qrem == 0), no stream switch in either iteration (krem >= 2) and, under the causal mask, FULL
             # bodies without a diagonal tile (wrem = krem - 2 + wave >= 3).  A lean iteration issues the same DMA pieces and meets the
@@ -1494,7 +1494,7 @@ class Gen:
                 self.i(f"s_sub_u32 {S(c)}, {S(c)}, 2")
             self.i(f"s_branch {lloop}")
             self.lab(lgen)
-        use_seam = SEAM and not STAMP
+        use_seam = SEAM and STAMP in (0, 3)
         lseam = f".L{n}_seam"
         for p in (0, 1):
             lnf, ll, ld = (self.ul(x) for x in ("notfull", "last", "done"))

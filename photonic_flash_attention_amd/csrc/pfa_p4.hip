@@ -94,7 +94,8 @@ const DevMod* module_for(int dev) {
                             snprintf(name, sizeof(name), "fa3_fwd_p4_%s_d%d_%s%s_%s", dt[d], hd ? 64 : 128, cz[c], km ? "_km" : "", pv[v]);
                             if (hipModuleGetFunction(&m.fn[d][hd][c][km][v], m.mod, name) != hipSuccess) {
                                 (void)hipGetLastError();
-                                return nullptr;
+                                m.fn[d][hd][c][km][v] = nullptr;
+                                if (!km) return nullptr;          // (a diagnostic P4_STAMP build carries no key-mask kernels: those problems stay on the HIP kernels)
                             }
                         }
         m.state = 1;
@@ -137,6 +138,7 @@ bool p4_eligible(const pfa_fa3_args* a) {
 int p4_workgroups(const pfa_fa3_args* a) {
     const DevMod* m = module_for(a->device_id);
     if (!m) return 0;
+    if (!m->fn[a->dtype_in == PFA_DTYPE_BF16 ? 0 : 1][a->D == 64 ? 1 : 0][a->causal ? 1 : 0][a->key_mask ? 1 : 0][a->dtype_out == PFA_DTYPE_FP32 ? 1 : 0]) return 0;
     const int BH = a->B * a->H;
     return BH % 8 == 0 ? (m->n_cu / 8) * 8 : m->n_cu;
 }

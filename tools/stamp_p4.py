@@ -22,6 +22,11 @@ for name in (sys.argv[1:] or ["C3", "C4"]):
     acc = d[..., 1:]                       # bucket k at index k
     nfull, nitems = acc[..., 7].sum(), acc[..., 8].sum()
     tot = acc[..., 10]
+    if nfull == 0:                         # P4_STAMP=3: kernel totals only (the production control flow: lean loop, pipelined seam)
+        clk = (tot / (acc[..., 11] * 10e-9) / 1e9)
+        print(f"{name}: kernel cycles per wave: mean {tot.mean():.0f} (min {tot.min():.0f} max {tot.max():.0f}); in-kernel clock {clk.mean():.3f} GHz; "
+              f"wall per wave {acc[..., 11].mean() * 10 / 1e3:.1f} us (max {acc[..., 11].max() * 10 / 1e3:.1f})")
+        continue
     print(f"{name}: FULL iterations {int(nfull)}, items {int(nitems)} (per workgroup-wave)")
     print(f"  per FULL iteration: QK^T phase {acc[..., 0].sum() / nfull:7.0f}   PV phase {acc[..., 1].sum() / nfull:7.0f} cycles")
     print(f"  wait + barrier + bookkeeping (all iterations) {acc[..., 2].sum() / nfull:7.0f} per FULL iteration")
