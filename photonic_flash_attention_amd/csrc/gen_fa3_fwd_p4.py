@@ -161,11 +161,19 @@ class Lgkm:
 
 
 class Gen:
-    def __init__(self, dtype, causal, out32=False, split=False, D=128, kmask=False):
+    def __init__(self, dtype, causal, out32=False, split=False, D=128, kmask=False, klen=False):
         """out32: fp32 store (straight from the accumulators); split: P enters the PV product as a 16-bit hi + lo pair (two MFMAs per
         fragment, P's rounding error 2^-18 instead of 2^-9): together the <= 1e-3 parity variant on the benched schedule."""
         assert out32 == split, "the code object carries the fast variant (16-bit store, one P) and the parity variant (fp32 store, split P)"
         self.dt, self.causal, self.out32, self.split, self.kmask = dtype, causal, out32, split, kmask
+        # klen: RAGGED problems -- Sq / Sk are no multiples of the block / tile.  Rows past the end are kept out by the buffer
+        # descriptors (K / V: the whole slab as ever; Q / O / LSE: records per item = the block's existing rows; a raw buffer's range
+        # check is offset >= records - scalar offset, so the tile / group / row-group offsets riding in scalar offsets are covered:
+        # loads past the end give zeros, stores past it are dropped), keys past Sk by a mask word computed from the length (not
+        # needed under the causal mask: a valid row never looks that far).
+        self.klen = klen
+        assert not (kmask and klen)
+        self.mwords = kmask or (klen and not causal)
         assert not (kmask and STAMP), "the key-mask kernels keep their mask words where the stamps keep their clock (s[58:59], the dbg kernarg)"
         assert D in (64, 128)
         self.D, self.KS, self.DB = D, D // 16, D // 32                 # head dim, k-steps of QK^T, 32-wide d blocks of PV
@@ -179,7 +187,7 @@ class Gen:
         self.RING = min(RING, self.NKF)
         self.mf = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
-        self.name = f"fa3_fwd_p4_{dtype}_d{D}_{'causal' if causal else 'full'}{'_km' if kmask else ''}_{'splitp_o32' if out32 else 'o16'}"
+        self.name = f"fa3_fwd_p4_{dtype}_d{D}_{'causal' if causal else 'full'}{'_km' if kmask else ('_kl' if klen else '')}_{'splitp_o32' if out32 else 'o16'}"
         self.main, self.ool = [], []
         self.L = self.main
         self.abl_on = False
@@ -292,6 +300,15 @@ class Gen:
     def MK(i):
         return "s[58:59]" if i == 0 else "s[100:101]"
 
+    def len_word(self, i):
+        """klen, no causal mask: MK(i) = the low min(64, max(0, pad)) bits, pad = keys left from the tile in question on."""
+        t0 = S('t0')
+        self.i(f"s_max_i32 {t0}, {ka('pad')}, 0")
+        self.i(f"s_min_i32 {t0}, {t0}, 63")
+        self.i(f"s_bfm_b64 {self.MK(i)}, {t0}, 0")
+        self.i(f"s_cmp_ge_i32 {ka('pad')}, 64")
+        self.i(f"s_cselect_b64 {self.MK(i)}, -1, {self.MK(i)}")
+
     def mask_load(self, n=0):
         v = vr(self.KM_V[n])
         return [f"v_add_u32 {v}, {ka('pad')}, {vr(V_LANE)}", f"global_load_ubyte {v}, {v}, {ka('dbg', 2)}"]
@@ -302,7 +319,7 @@ class Gen:
     def mask_keys(self, buf, i):
         """S of buffer `buf` (both strips) under the mask word MK(i): nothing to do when all 64 keys are visible (the common tile of a
         padding mask), else -inf per masked key: key 32 kb + kidx(e) + 4 h of register e -- bit b for the lower lane half, b + 4 for the upper."""
-        if not self.kmask:
+        if not self.mwords:
             return
         lm, lr = self.ul("kmask"), self.ul("kmasked")
         self.i(f"s_cmp_eq_u64 {self.MK(i)}, -1")
@@ -575,9 +592,13 @@ class Gen:
         self.i(f"s_mov_b32 {S('krem')}, {S('nt_n')}")
         if self.kmask:                                                  # ... and so are its mask bytes: row n_b
             self.i(f"s_mul_i32 {ka('pad')}, {S('n_b')}, {ka('Sk')}")
+        if self.klen and not self.causal:
+            self.i(f"s_mov_b32 {ka('pad')}, {ka('Sk')}")                 # keys left from tile j+2 on
         self.lab(l1)
         if self.kmask:
             self.emit(self.mask_load())                                 # the bytes of tile j+2 (its K pieces go to slot p in this iteration)
+        if self.klen and not self.causal:
+            self.len_word(p)                                            # the word of tile j+2 from the keys left
         self.i(f"s_cmp_lg_u32 {S('vrem')}, 0")
         self.i(f"s_cbranch_scc1 {l2}")
         self.i(f"s_mov_b64 {S('vsrd', 0, 2)}, {S('vsrd_n')}")
@@ -595,6 +616,8 @@ class Gen:
         self.i(f"s_sub_u32 {S('wrem')}, {S('wrem')}, 1")
         if self.kmask:
             self.i(f"s_add_u32 {ka('pad')}, {ka('pad')}, 64")
+        if self.klen and not self.causal:
+            self.i(f"s_sub_u32 {ka('pad')}, {ka('pad')}, 64")
         self.i(f"s_cmp_lg_u32 {S('qrem')}, 0")
         self.i(f"s_cbranch_scc1 {lq}")
         self.stamp(2, fine=True)
@@ -699,7 +722,8 @@ class Gen:
         pre, fin = fin[:npre], fin[npre:]
         lg = self.run_phase(self.phase_qk, fin, Lgkm(), p=p, dma_at=dma, pre=pre, tail_vreads=p)
         self.stamp(0, fine=True)
-        self.mask_keys(1 - p, 1 - p)           # tile j+1: buffer 1-p, word MK((j+1) & 1)
+        if not (lean and self.klen):           # (klen: a lean iteration is that far from the last tiles that all its keys exist)
+            self.mask_keys(1 - p, 1 - p)       # tile j+1: buffer 1-p, word MK((j+1) & 1)
         if self.causal and not lean:           # the diagonal tile of this wave is tile wnt-1 = j+1  <=>  wrem == 1
             lm, lr = self.ul("mask"), self.ul("masked")
             self.i(f"s_cmp_eq_u32 {S('wrem')}, 1")
@@ -863,7 +887,21 @@ class Gen:
         self.i(f"s_add_u32 {lo}, {lo}, {ka('q')}")
         self.i(f"s_addc_u32 {hi}, {hi}, {ka('q', hi=True)}")
         self.i(f"s_and_b32 {hi}, {hi}, 0xffff")
+        if self.klen:                          # records = the block's rows that exist
+            self.block_records(S('qsrd_n', 2), S('n_qblk'), 'q_ss', self.RB, t3)
         self.lab(ln)
+
+    def block_records(self, dst, qblk, ss, row_bytes, tmp):
+        """dst = (min(256, Sq - 256 qblk) - 1) * stride + row bytes   (klen: descriptors that end with the block's last existing row)"""
+        self.i(f"s_lshl_b32 {tmp}, {qblk}, 8")
+        self.i(f"s_sub_u32 {tmp}, {ka('Sq')}, {tmp}")
+        self.i(f"s_min_u32 {tmp}, {tmp}, 256")
+        self.i(f"s_sub_u32 {tmp}, {tmp}, 1")
+        if isinstance(ss, str):
+            self.i(f"s_mul_i32 {tmp}, {tmp}, {ka(ss)}")
+        else:
+            self.i(f"s_mul_i32 {tmp}, {tmp}, {ss}")
+        self.i(f"s_add_u32 {dst}, {tmp}, {row_bytes}")
 
     def make_out_srds(self):
         """osrd / lsrd of the item that becomes current, from n_b / n_hh / n_qblk (before the next decode overwrites them)."""
@@ -894,6 +932,9 @@ class Gen:
         self.i(f"s_add_u32 {S('lsrd', 0)}, {ka('lse')}, {t3}")
         self.i(f"s_addc_u32 {S('lsrd', 1)}, {ka('lse', hi=True)}, {th}")
         self.i(f"s_and_b32 {S('lsrd', 1)}, {S('lsrd', 1)}, 0xffff")
+        if self.klen:                          # both end with the block's last existing row
+            self.block_records(S('osrd', 2), S('n_qblk'), 'o_ss', self.RB * (2 if self.out32 else 1), t3)
+            self.block_records(S('lsrd', 2), S('n_qblk'), 4, 4, t3)
 
     def zero_o(self):
         """O = 0 on the matrix pipe: one MFMA of zero operands per 16 accumulator registers (8 instructions instead of 128 writes)."""
@@ -1432,6 +1473,10 @@ class Gen:
             self.i(f"s_add_u32 {ka('pad')}, {ka('pad')}, 64")
             self.emit(self.mask_load(1))
             self.i(f"s_add_u32 {ka('pad')}, {ka('pad')}, 64")                     # next: tile 2
+        if self.klen and not self.causal:      # tiles 0 and 1 are whole (Sk > 192); keys left from tile 2 on
+            self.i(f"s_mov_b64 {self.MK(0)}, -1")
+            self.i(f"s_mov_b64 {self.MK(1)}, -1")
+            self.i(f"s_sub_u32 {ka('pad')}, {ka('Sk')}, 128")
         self.i(f"s_mov_b32 {S('qrem')}, {self.PPW}")
         for g in range(self.PPW):                # the wave's 64 rows, 4 KiB a group
             self.q_group()
@@ -1474,7 +1519,7 @@ class Gen:
             # pieces left to request (qrem == 0), no stream switch in either iteration (krem >= 2) and, under the causal mask, FULL
             # bodies without a diagonal tile (wrem = krem - 2 + wave >= 3).  A lean iteration issues the same DMA pieces and meets the
             # same barriers as a generic one, so every wave decides for itself.  (17 scalar instructions a tile were ~9 % of it.)
-            self.i(f"s_cmp_lt_u32 {S('krem')}, {5 if self.causal else 2}")
+            self.i(f"s_cmp_lt_u32 {S('krem')}, {5 if self.causal else (4 if self.klen else 2)}")      # (klen: tiles j+2, j+3 whole too)
             self.i(f"s_cbranch_scc1 {lgen}")
             self.i(f"s_cmp_lg_u32 {S('qrem')}, 0")
             self.i(f"s_cbranch_scc1 {lgen}")
@@ -1492,6 +1537,10 @@ class Gen:
                 self.i("s_barrier")
             for c in ("krem", "vrem", "wrem", "irem"):
                 self.i(f"s_sub_u32 {S(c)}, {S(c)}, 2")
+            if self.klen and not self.causal:       # the words of tiles j+2, j+3 (all keys exist), the keys left behind them
+                self.i(f"s_mov_b64 {self.MK(0)}, -1")
+                self.i(f"s_mov_b64 {self.MK(1)}, -1")
+                self.i(f"s_sub_u32 {ka('pad')}, {ka('pad')}, 128")
             self.i(f"s_branch {lloop}")
             self.lab(lgen)
         use_seam = SEAM and STAMP in (0, 3)
@@ -1610,7 +1659,7 @@ class Gen:
 def kernels():
     """(dtype, causal, parity): parity = fp32 store + split P (the <= 1e-3 variant on the same schedule)"""
     return [(dt, D, causal, km, par) for dt in ("bf16", "fp16") for D in (128, 64) for causal in (True, False)
-            for km in ((False,) if STAMP else (False, True)) for par in (False, True)]
+            for km in (("",) if STAMP else ("", "km", "kl")) for par in (False, True)]
 
 
 def main():
@@ -1624,7 +1673,7 @@ def main():
     out = ['\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"', "\t.amdhsa_code_object_version 6", "\t.text"]
     meta = []
     for dt, D, causal, km, par in kernels():
-        g = Gen(dt, causal, out32=par, split=par, D=D, kmask=km)
+        g = Gen(dt, causal, out32=par, split=par, D=D, kmask=km == "km", klen=km == "kl")
         g.kernel()
         out += g.main
         out.append(g.descriptor())

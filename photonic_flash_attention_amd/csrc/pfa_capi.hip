@@ -90,7 +90,7 @@ Variant p4_variant(const pfa_fa3_args* a, bool causal) {
     Variant v;
     v.fn = nullptr;
     snprintf(v.name, sizeof(v.name), "fa3_fwd_p4_%s_d%d_%s%s_%s", a->dtype_in == PFA_DTYPE_BF16 ? "bf16" : "fp16", a->D, causal ? "causal" : "full",
-             a->key_mask ? "_km" : "", a->dtype_out == PFA_DTYPE_FP32 ? "splitp_o32" : "o16");
+             pfa::p4_flavour(a) == 1 ? "_km" : (pfa::p4_flavour(a) == 2 ? "_kl" : ""), a->dtype_out == PFA_DTYPE_FP32 ? "splitp_o32" : "o16");
     v.p4 = true;
     v.p4_grid = pfa::p4_workgroups(a);
     v.lds_bytes = 0;
@@ -136,7 +136,7 @@ Variant pick(const pfa_fa3_args* a) {
         // D = 64: the tile loop is bound by the softmax's vector instructions (half the MFMA work under the same exponentials), where
         // two waves per SIMD (the 8-wave HIP kernel) overlap better than one: the persistent kernel only wins while every unit has a CU
         // of its own, i.e. no item seam (same box: C2 +3 %, 256 units +2 %; 384 units -9 %, 1024 units -8 %).  Selector 45 forces it.
-        const int64_t units = (int64_t)a->B * a->H * (a->Sq / 256) / (causal ? 2 : 1);
+        const int64_t units = (int64_t)a->B * a->H * ((a->Sq + 255) / 256) / (causal ? 2 : 1);
         const bool take = a->D == 128 || var == 45 || units <= v.p4_grid;
         if (v.p4_grid > 0 && take) return v;   // (0: the code object did not load on this device -- fall through to the HIP kernels)
     }

@@ -56,7 +56,7 @@ namespace {
 constexpr int MAX_DEV = 64;
 struct DevMod {
     hipModule_t mod = nullptr;
-    hipFunction_t fn[2][2][2][2][2] = {};  // [dtype][D: 128, 64][causal][key mask][parity variant: fp32 store + split P]
+    hipFunction_t fn[2][2][2][3][2] = {};  // [dtype][D: 128, 64][causal][plain, key mask, ragged][parity variant: fp32 store + split P]
     int n_cu = 0;
     int state = 0;                   // 0 = not tried, 1 = ready, -1 = failed
 };
@@ -88,10 +88,10 @@ const DevMod* module_for(int dev) {
         for (int d = 0; d < 2; ++d)
             for (int hd = 0; hd < 2; ++hd)
                 for (int c = 0; c < 2; ++c)
-                    for (int km = 0; km < 2; ++km)
+                    for (int km = 0; km < 3; ++km)
                         for (int v = 0; v < 2; ++v) {
                             char name[64];
-                            snprintf(name, sizeof(name), "fa3_fwd_p4_%s_d%d_%s%s_%s", dt[d], hd ? 64 : 128, cz[c], km ? "_km" : "", pv[v]);
+                            snprintf(name, sizeof(name), "fa3_fwd_p4_%s_d%d_%s%s_%s", dt[d], hd ? 64 : 128, cz[c], km == 1 ? "_km" : (km == 2 ? "_kl" : ""), pv[v]);
                             if (hipModuleGetFunction(&m.fn[d][hd][c][km][v], m.mod, name) != hipSuccess) {
                                 (void)hipGetLastError();
                                 m.fn[d][hd][c][km][v] = nullptr;
@@ -106,6 +106,14 @@ const DevMod* module_for(int dev) {
 bool fits_u32(int64_t x) { return x >= 0 && x <= 0xffffffffLL; }
 }  // namespace
 
+// 0 = the plain kernels (whole blocks and tiles), 1 = *_km_* ([B, Sk] key mask, whole blocks and tiles), 2 = *_kl_* (ragged: Sq no
+// multiple of 256 or Sk no multiple of 128 -- rows past the end are kept out by buffer descriptors, keys past Sk by a computed mask word)
+int p4_flavour(const pfa_fa3_args* a) {
+    if (a->key_mask) return 1;
+    const bool whole = a->Sq % 256 == 0 && a->Sk % 128 == 0 && (!a->causal || (a->Sq / 256) % 2 == 0);
+    return whole ? 0 : 2;
+}
+
 // Shapes the persistent kernel takes (everything else stays on the HIP kernels): D = 128 or 64; the fast variant (one P operand, 16-bit
 // store) or the parity variant (split P AND fp32 store); no element mask / seqlens (a [B, Sk] key mask with contiguous rows is read
 // by the kernel itself, 64 bytes per wave and tile: the *_km_* kernels), whole 256-row Q blocks and an even number of 64-key
@@ -117,8 +125,10 @@ bool p4_eligible(const pfa_fa3_args* a) {
     const int64_t osz = out32 ? 4 : 2;
     if (a->mask || a->seqlens_k) return false;
     if (a->key_mask && (a->key_mask_stride_b != a->Sk || (int64_t)a->B * a->Sk > 0x7fffffffLL)) return false;   // its 32-bit running byte offset
-    if (a->Sq % 256 != 0 || a->Sk % 128 != 0 || a->Sk < 256) return false;
-    if (a->causal && (a->Sq != a->Sk || (a->Sq / 256) % 2 != 0)) return false;
+    const int64_t NBq = ((int64_t)a->Sq + 255) / 256;
+    if (a->key_mask && (a->Sq % 256 != 0 || a->Sk % 128 != 0)) return false;          // (the mask bytes of a tile past Sk do not exist)
+    if (a->Sq < 128 || a->Sk < 193) return false;      // at least half a Q block of rows; at least four key tiles, the first three of them whole
+    if (a->causal && (a->Sq != a->Sk || NBq % 2 != 0)) return false;                   // units are (heavy, light) block pairs
     const int64_t st[] = {a->q_stride_b, a->q_stride_h, a->q_stride_s, a->k_stride_b, a->k_stride_h, a->k_stride_s,
                           a->v_stride_b, a->v_stride_h, a->v_stride_s};
     for (int64_t s : st)
@@ -130,7 +140,7 @@ bool p4_eligible(const pfa_fa3_args* a) {
     if (256 * a->q_stride_s * 2 > 0x7fffffffLL || 256 * a->o_stride_s * osz > 0x7fffffffLL) return false;
     if ((a->o_stride_s * osz) % 16 != 0 || (a->o_stride_h * osz) % 16 != 0 || (a->o_stride_b * osz) % 16 != 0 ||
         (reinterpret_cast<uintptr_t>(a->o) & 15u)) return false;                                       // 16-byte row stores
-    const int64_t BH = (int64_t)a->B * a->H, NB = a->Sq / 256, NU = a->causal ? NB / 2 : NB;
+    const int64_t BH = (int64_t)a->B * a->H, NB = NBq, NU = a->causal ? NB / 2 : NB;
     if (BH * NU > (1ll << 24) || BH * a->H >= (1ll << 32)) return false;                                 // multiply-high ranges
     return true;
 }
@@ -138,7 +148,7 @@ bool p4_eligible(const pfa_fa3_args* a) {
 int p4_workgroups(const pfa_fa3_args* a) {
     const DevMod* m = module_for(a->device_id);
     if (!m) return 0;
-    if (!m->fn[a->dtype_in == PFA_DTYPE_BF16 ? 0 : 1][a->D == 64 ? 1 : 0][a->causal ? 1 : 0][a->key_mask ? 1 : 0][a->dtype_out == PFA_DTYPE_FP32 ? 1 : 0]) return 0;
+    if (!m->fn[a->dtype_in == PFA_DTYPE_BF16 ? 0 : 1][a->D == 64 ? 1 : 0][a->causal ? 1 : 0][p4_flavour(a)][a->dtype_out == PFA_DTYPE_FP32 ? 1 : 0]) return 0;
     const int BH = a->B * a->H;
     return BH % 8 == 0 ? (m->n_cu / 8) * 8 : m->n_cu;
 }
@@ -157,7 +167,7 @@ int p4_launch(const pfa_fa3_args* a, void* stream, int* hip_err) {
     const int64_t osz = parity ? 4 : 2;
     p.o_sb = (uint32_t)(a->o_stride_b * osz); p.o_sh = (uint32_t)(a->o_stride_h * osz); p.o_ss = (uint32_t)(a->o_stride_s * osz);
     p.H = (uint32_t)a->H; p.Sq = (uint32_t)a->Sq; p.Sk = (uint32_t)a->Sk;
-    p.NB = (uint32_t)(a->Sq / 256);
+    p.NB = (uint32_t)((a->Sq + 255) / 256);
     p.NU = a->causal ? p.NB / 2 : p.NB;
     p.magic_NU = magic(p.NU); p.magic_H = magic(p.H);
     p.kv_group = a->kv_group > 1 ? (uint32_t)a->kv_group : 1u;
@@ -169,7 +179,7 @@ int p4_launch(const pfa_fa3_args* a, void* stream, int* hip_err) {
     p.xcd_mode = BH % 8 == 0 ? 1u : 0u;
     p.hx = p.xcd_mode ? (uint32_t)(BH / 8) : (uint32_t)BH;
     p.SL = p.xcd_mode ? (uint32_t)(grid / 8) : (uint32_t)grid;
-    p.nt_full = (uint32_t)(a->Sk / 64);
+    p.nt_full = (uint32_t)(((a->Sk + 127) / 128) * 2);          // 64-key tiles, an even number of them (the two S buffers alternate from tile 0)
     // diagnostic build only (P4_STAMP=1 make): per-wave cycle buckets go to the caller's workspace; the production kernel never reads it
     p.dbg = (a->workspace && a->workspace_bytes >= (size_t)grid * 4 * 16 * 4) ? (unsigned long long*)a->workspace : nullptr;
     // key-mask kernels: the same kernarg slot carries the mask bytes, `pad` is the kernel's running byte offset into them
@@ -177,7 +187,7 @@ int p4_launch(const pfa_fa3_args* a, void* stream, int* hip_err) {
 
     size_t sz = sizeof(p);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
-    hipFunction_t fn = m->fn[a->dtype_in == PFA_DTYPE_BF16 ? 0 : 1][a->D == 64 ? 1 : 0][a->causal ? 1 : 0][a->key_mask ? 1 : 0][parity ? 1 : 0];
+    hipFunction_t fn = m->fn[a->dtype_in == PFA_DTYPE_BF16 ? 0 : 1][a->D == 64 ? 1 : 0][a->causal ? 1 : 0][p4_flavour(a)][parity ? 1 : 0];
     int prev = -1;
     hipError_t e = hipGetDevice(&prev);
     if (e == hipSuccess && prev != a->device_id) e = hipSetDevice(a->device_id);

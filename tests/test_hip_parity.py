@@ -475,6 +475,41 @@ def test_p4_key_mask_kernels_against_the_oracle(case, kind):
     assert "p4" not in _capi.describe(a)[0]
 
 
+@pytest.mark.parametrize("case", [(1, 8, 300, 300, False, 128), (2, 4, 257, 193, False, 128), (1, 8, 1000, 1000, True, 128), (2, 3, 512, 1000, False, 128),
+                                  (2, 8, 1024, 1025, False, 128), (1, 8, 129, 2000, False, 128), (2, 4, 1500, 1500, True, 64), (3, 5, 700, 640, False, 64)])
+def test_p4_ragged_kernels_against_the_oracle(case):
+    """Sq no multiple of 256 / Sk no multiple of 128 on the persistent schedule (fa3_fwd_p4_*_kl_*): against the oracle, against the
+    8-wave kernel, and nothing read or written outside the tensors (NaN guard rows around q / k / v, sentinel rows around out / lse)."""
+    from oracle import fa3_oracle as orc
+    from photonic_flash_attention_amd import _capi, ops, synth
+    B, H, Sq, Sk, causal, D = case
+    q, k, v = synth.qkv(B, H, Sq, Sk, D, 4800 + Sq + Sk, "bf16")                     # [B,S,H,D]
+    G = 2
+
+    def guarded(t, fill):
+        buf = torch.full((t.shape[0], t.shape[1] + 2 * G) + tuple(t.shape[2:]), fill, dtype=t.dtype, device="cuda:0")
+        buf[:, G:-G] = t.to("cuda:0")
+        return buf
+    qb, kb, vb = (guarded(t, float("nan")) for t in (q, k, v))
+    qd, kd, vd = (t[:, G:-G].permute(0, 2, 1, 3) for t in (qb, kb, vb))
+    ob16 = torch.full((B, Sq + 2 * G, H, D), 7.0, device="cuda:0", dtype=torch.bfloat16)
+    ob32 = torch.full((B, Sq + 2 * G, H, D), 7.0, device="cuda:0", dtype=torch.float32)
+    o16, lse = ops.fa3_forward(qd, kd, vd, causal=causal, out=ob16[:, G:-G].permute(0, 2, 1, 3), return_lse=True)
+    o32, _ = ops.fa3_forward(qd, kd, vd, causal=causal, out=ob32[:, G:-G].permute(0, 2, 1, 3), out_dtype=torch.float32)
+    o44, l44 = ops.fa3_forward(qd, kd, vd, causal=causal, out_dtype=torch.float32, return_lse=True, _variant=44)
+    torch.cuda.synchronize()
+    name = _capi.describe(ops.build_args(qd, kd, vd, o16, causal=causal)[0])[0]
+    assert name == f"fa3_fwd_p4_bf16_d{D}_{'causal' if causal else 'full'}_kl_o16", name          # picked without a selector
+    for ob in (ob16, ob32):
+        assert bool((ob[:, :G] == 7.0).all()) and bool((ob[:, -G:] == 7.0).all())
+    ref = orc.attention_bshd(q, k, v, causal=causal)
+    err = float((o32.permute(0, 2, 1, 3).cpu() - ref).abs().max())
+    assert err <= PARITY_TOL, (case, err)
+    assert float((o32 - o44).abs().max()) <= 3e-5 and float((lse - l44).abs().max()) <= 2e-5
+    assert _fast_ok(o16.permute(0, 2, 1, 3).float().cpu(), ref, _pnorm(q, k, causal), float(v.float().abs().max()), "bf16", tag=f"p4 ragged {case}")
+    assert float((lse.cpu() - orc.lse_bshd(q, k, causal=causal)).abs().max()) <= 2e-3
+
+
 def test_p4_kernel_reads_fused_qkv_views_and_is_the_default_for_long_aligned_problems():
     from oracle import fa3_oracle as orc
     from photonic_flash_attention_amd import _capi, ops, synth
@@ -490,9 +525,13 @@ def test_p4_kernel_reads_fused_qkv_views_and_is_the_default_for_long_aligned_pro
     qc, kc, vc = (t.transpose(1, 2).float().cpu().contiguous() for t in (q, k, v))
     ref = orc.attention_bshd(qc, kc, vc)
     assert _fast_ok(out.permute(0, 2, 1, 3).float().cpu(), ref, _pnorm(qc, kc, False), float(v.float().abs().max()))
-    # not eligible -> the HIP kernels: ragged lengths, masks, fp32 stores, short sequences
+    # ragged lengths: the *_kl_* kernels (rows past the end kept out by the buffer descriptors, keys past Sk by a computed mask word)
     q2, k2, v2 = (t[:, :, :2000] for t in (q, k, v))
-    assert "p4" not in _capi.describe(ops.build_args(q2, k2, v2, out[:, :, :2000], causal=False)[0])[0]
+    assert _capi.describe(ops.build_args(q2, k2, v2, out[:, :, :2000], causal=False)[0])[0] == "fa3_fwd_p4_bf16_d128_full_kl_o16"
+    # not eligible -> the HIP kernels: short key sequences, an odd number of Q blocks under the causal mask, element masks, seqlens, fp32 store with one P
+    assert "p4" not in _capi.describe(ops.build_args(q2, k2[:, :, :192], v2[:, :, :192], out[:, :, :2000], causal=False)[0])[0]
+    q3, k3, v3 = (t[:, :, :700] for t in (q, k, v))
+    assert "p4" not in _capi.describe(ops.build_args(q3, k3, v3, out[:, :, :700], causal=True)[0])[0]
     o32 = torch.empty(B, S, H, D, device="cuda:0", dtype=torch.float32).permute(0, 2, 1, 3)
     assert _capi.describe(ops.build_args(q, k, v, o32, causal=False, split_p=True)[0])[0] == "fa3_fwd_p4_bf16_d128_full_splitp_o32"
     assert "p4" not in _capi.describe(ops.build_args(q, k, v, o32, causal=False, split_p=False)[0])[0]      # fp32 store, one P: HIP kernel
@@ -513,9 +552,11 @@ def test_p4_kernel_random_eligible_shapes():
         causal = rnd.random() < 0.5
         B, H = rnd.choice([(1, 1), (1, 8), (2, 3), (1, 24), (4, 8), (1, 40)])
         if causal:
-            Sq = Sk = 512 * rnd.randint(1, 4)
+            Sq = Sk = 512 * rnd.randint(1, 4) - (rnd.randint(0, 255) if it % 3 == 0 else 0)
         else:
             Sq, Sk = 256 * rnd.randint(1, 6), 128 * rnd.randint(2, 12)
+            if it % 3 == 0:
+                Sq, Sk = max(128, Sq - rnd.randint(0, 255)), max(193, Sk - rnd.randint(0, 127))
         dtype = rnd.choice(["bf16", "fp16"])
         D = rnd.choice([128, 64])
         q, k, v = (t.to("cuda:0").permute(0, 2, 1, 3) for t in synth.qkv(B, H, Sq, Sk, D, 12000 + it, dtype))
