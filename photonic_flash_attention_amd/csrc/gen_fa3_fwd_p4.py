@@ -35,7 +35,9 @@ import sys
 KA = dict(q=0, k=2, v=4, o=6, lse=8, q_sb=10, q_sh=11, k_sb=12, k_sh=13, v_sb=14, v_sh=15, o_sb=16, o_sh=17,
           q_ss=18, k_ss=19, v_ss=20, o_ss=21, H=22, Sq=23, Sk=24, NB=25, NU=26, magic_NU=27, magic_H=28, kv_group=29,
           magic_G=30, scale_log2=31, thr=32, hx=33, xcd_mode=34, SL=35, nt_full=36, pad=37, dbg=38)
-KARG_DWORDS = 40
+KARG_DWORDS = 40                    # preloaded into s[60:99]
+KARG_MEM_DWORDS = 42                # ... of the kernarg block's 42: dwords 40 / 41 = seqlens_k, fetched where it is needed (decode)
+KA_SEQLENS = 40
 KBASE_SGPR = 60                     # kernargs live in s[60:99]
 
 
@@ -69,7 +71,7 @@ for nm, n, al in [("wave", 1, 1), ("ksrd", 4, 4), ("vsrd", 4, 4), ("qsrd_n", 4, 
                   ("ksrd_n", 2, 2), ("vsrd_n", 2, 2), ("grow", 2, 2), ("t2", 2, 2),
                   ("koff", 1, 1), ("voff", 1, 1), ("ktile", 1, 1), ("vtile", 1, 1), ("krem", 1, 1), ("vrem", 1, 1),
                   ("qrem", 1, 1), ("wrem", 1, 1), ("irem", 1, 1), ("nt_n", 1, 1), ("qdst", 1, 1), ("qoff", 1, 1),
-                  ("t0", 1, 1), ("t1", 1, 1), ("t3", 1, 1), ("w4k", 1, 1), ("xcd", 1, 1), ("slot", 1, 1), ("Ux", 1, 1),
+                  ("t0", 1, 1), ("t1", 1, 1), ("t3", 1, 1), ("w4k", 1, 1), ("xcd", 1, 1), ("slot", 1, 1), ("L_n", 1, 1),
                   ("n_u", 1, 1), ("n_sub", 1, 1), ("n_valid", 1, 1), ("n_qblk", 1, 1), ("n_b", 1, 1), ("n_hh", 1, 1), ("n_nt", 1, 1)]:
     S.new(nm, n, al)
 
@@ -300,14 +302,25 @@ class Gen:
     def MK(i):
         return "s[58:59]" if i == 0 else "s[100:101]"
 
-    def len_word(self, i):
-        """klen, no causal mask: MK(i) = the low min(64, max(0, pad)) bits, pad = keys left from the tile in question on."""
+    def len_word(self, i, dst=None, left=None):
+        """dst (default MK(i)) = the low min(64, max(0, left)) bits; left (default `pad`: klen, no causal mask) = keys left from the
+        tile in question on."""
         t0 = S('t0')
-        self.i(f"s_max_i32 {t0}, {ka('pad')}, 0")
+        dst, left = dst or self.MK(i), left or ka('pad')
+        self.i(f"s_max_i32 {t0}, {left}, 0")
         self.i(f"s_min_i32 {t0}, {t0}, 63")
-        self.i(f"s_bfm_b64 {self.MK(i)}, {t0}, 0")
-        self.i(f"s_cmp_ge_i32 {ka('pad')}, 64")
-        self.i(f"s_cselect_b64 {self.MK(i)}, -1, {self.MK(i)}")
+        self.i(f"s_bfm_b64 {dst}, {t0}, 0")
+        self.i(f"s_cmp_ge_i32 {left}, 64")
+        self.i(f"s_cselect_b64 {dst}, -1, {dst}")
+
+    def km_len_and(self, i):
+        """key-mask kernels without the causal mask: the word just made from the mask bytes AND the keys its batch has (seqlens_k;
+        Sk without it).  The keys left ride in `n_sub` (the causal kernels' sub-item flag: unused here)."""
+        if not (self.kmask and not self.causal):
+            return
+        self.len_word(i, dst=S('t2'), left=S('n_sub'))
+        self.i(f"s_and_b64 {self.MK(i)}, {self.MK(i)}, {S('t2')}")
+        self.i(f"s_sub_u32 {S('n_sub')}, {S('n_sub')}, 64")
 
     def mask_load(self, n=0):
         v = vr(self.KM_V[n])
@@ -592,8 +605,10 @@ class Gen:
         self.i(f"s_mov_b32 {S('krem')}, {S('nt_n')}")
         if self.kmask:                                                  # ... and so are its mask bytes: row n_b
             self.i(f"s_mul_i32 {ka('pad')}, {S('n_b')}, {ka('Sk')}")
+            if not self.causal:
+                self.i(f"s_mov_b32 {S('n_sub')}, {S('L_n')}")             # ... and the keys its batch has
         if self.klen and not self.causal:
-            self.i(f"s_mov_b32 {ka('pad')}, {ka('Sk')}")                 # keys left from tile j+2 on
+            self.i(f"s_mov_b32 {ka('pad')}, {S('L_n')}")                 # keys left from tile j+2 on
         self.lab(l1)
         if self.kmask:
             self.emit(self.mask_load())                                 # the bytes of tile j+2 (its K pieces go to slot p in this iteration)
@@ -626,6 +641,7 @@ class Gen:
         self.lab(lb)
         if self.kmask:
             self.i(self.mask_word(p))           # tile j+2 -> MK((j+2) & 1) = MK(p)
+            self.km_len_and(p)
         self.i("s_barrier")
         self.stamp(12, fine=True)               # bucket 12: the barrier
         self.out_of_line(True)
@@ -820,7 +836,8 @@ class Gen:
         # consecutive CUs at the same time)
         self.i(f"s_mul_i32 {u}, {S('n_u')}, {ka('SL')}")
         self.i(f"s_add_u32 {u}, {u}, {S('slot')}")
-        self.i(f"s_cmp_lt_u32 {u}, {S('Ux')}")
+        self.i(f"s_mul_i32 {t0}, {ka('hx')}, {ka('NU')}")                 # the units of this XCD's heads
+        self.i(f"s_cmp_lt_u32 {u}, {t0}")
         self.i(f"s_cbranch_scc1 {lv}")
         self.i(f"s_mov_b32 {S('n_nt')}, 0x7fffffff")
         self.i(f"s_mov_b32 {S('n_valid')}, 0")
@@ -889,6 +906,26 @@ class Gen:
         self.i(f"s_and_b32 {hi}, {hi}, 0xffff")
         if self.klen:                          # records = the block's rows that exist
             self.block_records(S('qsrd_n', 2), S('n_qblk'), 'q_ss', self.RB, t3)
+        if (self.klen or self.kmask) and not self.causal:
+            # seqlens_k (kernarg dwords 40 / 41, null = none): the item's keys L = clamp(seqlens_k[b], 0, Sk) and its tile count cut to them
+            # (an even number of tiles, at least 4): a padded batch does not compute its padding.  klen: L also feeds the length words.
+            lno = self.ul("noseqlens")
+            self.i(f"s_mov_b32 {S('L_n')}, {ka('Sk')}")
+            self.i(f"s_load_dwordx2 {S('t2')}, s[0:1], {4 * KA_SEQLENS}")
+            self.i("s_waitcnt lgkmcnt(0)")
+            self.i(f"s_cmp_eq_u64 {S('t2')}, 0")
+            self.i(f"s_cbranch_scc1 {lno}")
+            self.i(f"s_lshl_b32 {t0}, {S('n_b')}, 2")
+            self.i(f"s_load_dword {t0}, {S('t2')}, {t0}")
+            self.i("s_waitcnt lgkmcnt(0)")
+            self.i(f"s_max_i32 {t0}, {t0}, 0")
+            self.i(f"s_min_i32 {S('L_n')}, {t0}, {ka('Sk')}")
+            self.i(f"s_add_u32 {t0}, {S('L_n')}, 127")
+            self.i(f"s_lshr_b32 {t0}, {t0}, 7")
+            self.i(f"s_lshl_b32 {t0}, {t0}, 1")
+            self.i(f"s_max_u32 {t0}, {t0}, 4")
+            self.i(f"s_min_u32 {S('n_nt')}, {t0}, {ka('nt_full')}")
+            self.lab(lno)
         self.lab(ln)
 
     def block_records(self, dst, qblk, ss, row_bytes, tmp):
@@ -1431,7 +1468,6 @@ class Gen:
         self.i(f"s_cmp_eq_u32 {ka('xcd_mode')}, 0")
         self.i(f"s_cselect_b32 {S('xcd')}, 0, {S('xcd')}")
         self.i(f"s_cselect_b32 {S('slot')}, s2, {S('slot')}")
-        self.i(f"s_mul_i32 {S('Ux')}, {ka('hx')}, {ka('NU')}")
         self.i(f"s_lshl_b32 {S('ktile')}, {ka('k_ss')}, 6")
         self.i(f"s_lshl_b32 {S('vtile')}, {ka('v_ss')}, 6")
         self.i(f"s_lshl_b32 {S('w4k')}, {W}, {12 if self.D == 128 else 11}")         # the wave's quarter of a tile image
@@ -1473,10 +1509,12 @@ class Gen:
             self.i(f"s_add_u32 {ka('pad')}, {ka('pad')}, 64")
             self.emit(self.mask_load(1))
             self.i(f"s_add_u32 {ka('pad')}, {ka('pad')}, 64")                     # next: tile 2
-        if self.klen and not self.causal:      # tiles 0 and 1 are whole (Sk > 192); keys left from tile 2 on
-            self.i(f"s_mov_b64 {self.MK(0)}, -1")
-            self.i(f"s_mov_b64 {self.MK(1)}, -1")
-            self.i(f"s_sub_u32 {ka('pad')}, {ka('Sk')}, 128")
+        if self.klen and not self.causal:      # the words of tiles 0 and 1; keys left from tile 2 on
+            self.i(f"s_mov_b32 {ka('pad')}, {S('L_n')}")
+            self.len_word(0)
+            self.i(f"s_sub_u32 {ka('pad')}, {ka('pad')}, 64")
+            self.len_word(1)
+            self.i(f"s_sub_u32 {ka('pad')}, {ka('pad')}, 64")
         self.i(f"s_mov_b32 {S('qrem')}, {self.PPW}")
         for g in range(self.PPW):                # the wave's 64 rows, 4 KiB a group
             self.q_group()
@@ -1503,6 +1541,10 @@ class Gen:
         if self.kmask:
             self.i(self.mask_word(0, 0))
             self.i(self.mask_word(1, 1))
+            if not self.causal:
+                self.i(f"s_mov_b32 {S('n_sub')}, {S('L_n')}")
+                self.km_len_and(0)
+                self.km_len_and(1)
         self.i("s_barrier")
         litem = f".L{n}_item"
         self.lab(litem)
@@ -1519,7 +1561,7 @@ class Gen:
             # pieces left to request (qrem == 0), no stream switch in either iteration (krem >= 2) and, under the causal mask, FULL
             # bodies without a diagonal tile (wrem = krem - 2 + wave >= 3).  A lean iteration issues the same DMA pieces and meets the
             # same barriers as a generic one, so every wave decides for itself.  (17 scalar instructions a tile were ~9 % of it.)
-            self.i(f"s_cmp_lt_u32 {S('krem')}, {5 if self.causal else (4 if self.klen else 2)}")      # (klen: tiles j+2, j+3 whole too)
+            self.i(f"s_cmp_lt_u32 {S('krem')}, {5 if self.causal else (4 if (self.klen or self.kmask) else 2)}")      # (lengths: tiles j+2, j+3 whole too)
             self.i(f"s_cbranch_scc1 {lgen}")
             self.i(f"s_cmp_lg_u32 {S('qrem')}, 0")
             self.i(f"s_cbranch_scc1 {lgen}")
@@ -1537,6 +1579,8 @@ class Gen:
                 self.i("s_barrier")
             for c in ("krem", "vrem", "wrem", "irem"):
                 self.i(f"s_sub_u32 {S(c)}, {S(c)}, 2")
+            if self.kmask and not self.causal:      # (their words need no length: all keys exist)
+                self.i(f"s_sub_u32 {S('n_sub')}, {S('n_sub')}, 128")
             if self.klen and not self.causal:       # the words of tiles j+2, j+3 (all keys exist), the keys left behind them
                 self.i(f"s_mov_b64 {self.MK(0)}, -1")
                 self.i(f"s_mov_b64 {self.MK(1)}, -1")
@@ -1609,7 +1653,7 @@ class Gen:
 	.amdhsa_kernel {n}
 		.amdhsa_group_segment_fixed_size {self.LDS_BYTES}
 		.amdhsa_private_segment_fixed_size 0
-		.amdhsa_kernarg_size {4 * KARG_DWORDS}
+		.amdhsa_kernarg_size {4 * KARG_MEM_DWORDS}
 		.amdhsa_user_sgpr_count 2
 		.amdhsa_user_sgpr_kernarg_segment_ptr 1
 		.amdhsa_system_sgpr_workgroup_id_x 1
@@ -1637,11 +1681,11 @@ class Gen:
         return f"""  - .agpr_count:     256
     .args:
       - .offset:         0
-        .size:           {4 * KARG_DWORDS}
+        .size:           {4 * KARG_MEM_DWORDS}
         .value_kind:     by_value
     .group_segment_fixed_size: {self.LDS_BYTES}
     .kernarg_segment_align: 8
-    .kernarg_segment_size: {4 * KARG_DWORDS}
+    .kernarg_segment_size: {4 * KARG_MEM_DWORDS}
     .max_flat_workgroup_size: 256
     .name:           {n}
     .private_segment_fixed_size: 0
@@ -1666,7 +1710,8 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--offsets":       # the kernarg layout as a C header fragment (pfa_p4.hip static_asserts it)
         for k, v in KA.items():
             print(f"#define P4_KA_{k.upper()} {4 * v}")
-        print(f"#define P4_KARG_BYTES {4 * KARG_DWORDS}")
+        print(f"#define P4_KARG_BYTES {4 * KARG_MEM_DWORDS}")
+        print(f"#define P4_KA_SEQLENS {4 * KA_SEQLENS}")
         print(f"#define P4_LDS_BYTES_D128 {10 * 128 * 128}")
         print(f"#define P4_LDS_BYTES_D64 {10 * 128 * 64}")
         return

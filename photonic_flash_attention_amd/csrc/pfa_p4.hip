@@ -40,6 +40,7 @@ struct P4Params {
     float scale_log2, thr;
     uint32_t hx, xcd_mode, SL, nt_full, pad;
     unsigned long long* dbg;
+    const int32_t* seqlens_k;      // not preloaded by the kernel: fetched in its item decode (null = every batch has Sk keys)
 };
 #define P4_CHECK(field, macro) static_assert(offsetof(P4Params, field) == macro, "kernarg layout of " #field)
 P4_CHECK(q, P4_KA_Q); P4_CHECK(k, P4_KA_K); P4_CHECK(v, P4_KA_V); P4_CHECK(o, P4_KA_O); P4_CHECK(lse, P4_KA_LSE);
@@ -50,6 +51,7 @@ P4_CHECK(H, P4_KA_H); P4_CHECK(Sq, P4_KA_SQ); P4_CHECK(Sk, P4_KA_SK); P4_CHECK(N
 P4_CHECK(magic_NU, P4_KA_MAGIC_NU); P4_CHECK(magic_H, P4_KA_MAGIC_H); P4_CHECK(kv_group, P4_KA_KV_GROUP);
 P4_CHECK(magic_G, P4_KA_MAGIC_G); P4_CHECK(scale_log2, P4_KA_SCALE_LOG2); P4_CHECK(thr, P4_KA_THR); P4_CHECK(hx, P4_KA_HX);
 P4_CHECK(xcd_mode, P4_KA_XCD_MODE); P4_CHECK(SL, P4_KA_SL); P4_CHECK(nt_full, P4_KA_NT_FULL); P4_CHECK(dbg, P4_KA_DBG);
+P4_CHECK(seqlens_k, P4_KA_SEQLENS);
 static_assert(sizeof(P4Params) == P4_KARG_BYTES, "kernarg size");
 
 namespace {
@@ -111,19 +113,19 @@ bool fits_u32(int64_t x) { return x >= 0 && x <= 0xffffffffLL; }
 int p4_flavour(const pfa_fa3_args* a) {
     if (a->key_mask) return 1;
     const bool whole = a->Sq % 256 == 0 && a->Sk % 128 == 0 && (!a->causal || (a->Sq / 256) % 2 == 0);
-    return whole ? 0 : 2;
+    return whole && !a->seqlens_k ? 0 : 2;       // (per-batch key counts: the ragged kernels' length word, and tile counts cut to the length)
 }
 
 // Shapes the persistent kernel takes (everything else stays on the HIP kernels): D = 128 or 64; the fast variant (one P operand, 16-bit
-// store) or the parity variant (split P AND fp32 store); no element mask / seqlens (a [B, Sk] key mask with contiguous rows is read
-// by the kernel itself, 64 bytes per wave and tile: the *_km_* kernels), whole 256-row Q blocks and an even number of 64-key
-// tiles (the two S buffers alternate from tile 0 of every item), at least 4 tiles; under the causal mask Sq == Sk and an even
-// number of Q blocks (units are heavy + light block pairs).
+// store) or the parity variant (split P AND fp32 store); no element mask; Sq >= 128 and Sk >= 193 of any length (ragged: *_kl_*); a
+// [B, Sk] key mask with contiguous rows on whole blocks / tile pairs (*_km_*: the kernel reads the bytes itself); seqlens_k without the
+// causal mask (an item's tile count is cut to its batch's keys); under the causal mask Sq == Sk and an even number of Q blocks (units
+// are heavy + light block pairs).
 bool p4_eligible(const pfa_fa3_args* a) {
     const bool split = (a->flags & PFA_FLAG_SPLIT_P) != 0, out32 = a->dtype_out == PFA_DTYPE_FP32;
     if ((a->D != 128 && a->D != 64) || split != out32) return false;
     const int64_t osz = out32 ? 4 : 2;
-    if (a->mask || a->seqlens_k) return false;
+    if (a->mask || (a->seqlens_k && a->causal)) return false;      // (seqlens_k under the causal mask: the HIP kernels)
     if (a->key_mask && (a->key_mask_stride_b != a->Sk || (int64_t)a->B * a->Sk > 0x7fffffffLL)) return false;   // its 32-bit running byte offset
     const int64_t NBq = ((int64_t)a->Sq + 255) / 256;
     if (a->key_mask && (a->Sq % 256 != 0 || a->Sk % 128 != 0)) return false;          // (the mask bytes of a tile past Sk do not exist)
@@ -184,6 +186,7 @@ int p4_launch(const pfa_fa3_args* a, void* stream, int* hip_err) {
     p.dbg = (a->workspace && a->workspace_bytes >= (size_t)grid * 4 * 16 * 4) ? (unsigned long long*)a->workspace : nullptr;
     // key-mask kernels: the same kernarg slot carries the mask bytes, `pad` is the kernel's running byte offset into them
     if (a->key_mask) p.dbg = (unsigned long long*)a->key_mask;
+    p.seqlens_k = a->seqlens_k;
 
     size_t sz = sizeof(p);
     void* config[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &p, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};

@@ -118,6 +118,21 @@ def _as_mask4(mask: torch.Tensor, B: int, H: int, Sq: int, Sk: int, device) -> t
     return m
 
 
+_ARANGE1 = {}
+
+
+def _mask_bound(km: torch.Tensor) -> torch.Tensor:
+    """int32 [B]: 1 + the index of the last non-zero byte of every row of a [B, Sk] uint8 mask (0 for an empty row)."""
+    key = (km.shape[1], str(km.device))
+    with _SEQLENS_LOCK:
+        idx = _ARANGE1.get(key)
+        if idx is None:
+            if len(_ARANGE1) > 64:
+                _ARANGE1.clear()
+            idx = _ARANGE1[key] = torch.arange(1, km.shape[1] + 1, dtype=torch.int32, device=km.device)
+    return (idx * (km != 0)).amax(dim=1).to(torch.int32)
+
+
 def build_args(q, k, v, out, *, causal=False, seqlens_k=None, key_mask=None, softmax_scale=None,
                lse=None, split_p=False, variant=0, mask=None, drop_mask=None, drop_scale=1.0):
     """Fill a ``pfa_fa3_args`` from ``[B,H,S,D]``-shaped (arbitrarily strided) tensors."""
@@ -168,6 +183,15 @@ def build_args(q, k, v, out, *, causal=False, seqlens_k=None, key_mask=None, sof
         a.key_mask = km.data_ptr()
         a.key_mask_stride_b = km.stride(0)
         keep.append(km)
+        # A padding mask's tail is dead weight the kernel cannot see coming (it reads the bytes two tiles ahead): hand it, as seqlens_k,
+        # the position behind each row's LAST visible key -- two small device ops, no sync, nothing changes in the result (those keys are
+        # masked anyway) -- and the persistent kernel cuts every item's tile count to it.  Only where that kernel takes the problem and
+        # the launch is long enough to carry the two extra ops (>= ~0.15 ms of attention).
+        if (seqlens_k is None and not causal and q.dtype != torch.float32 and D in (64, 128) and Sq % 256 == 0 and Sk % 128 == 0
+                and 4.0 * B * H * Sq * Sk * D >= 1.5e11):
+            sl = _mask_bound(km)
+            a.seqlens_k = sl.data_ptr()
+            keep.append(sl)
     if mask is not None:
         if key_mask is not None:
             raise ValueError("pass either key_mask or mask")
