@@ -1434,10 +1434,23 @@ class Gen:
             self.i(f"s_sub_u32 {S('wrem')}, {S('n_nt')}, 1")
         self.make_out_srds()
         if self.causal:
+            # the next item: the unit's light block after its heavy one, else the next unit's heavy block.  With an odd number of
+            # blocks the last unit is the middle block alone (heavy == light: 2 qblk + 1 == NB): no second item.
+            lone, ldone = self.ul("loneblock"), self.ul("advanced")
+            self.i(f"s_lshl_b32 {S('t0')}, {S('n_qblk')}, 1")
+            self.i(f"s_add_u32 {S('t0')}, {S('t0')}, 1")
+            self.i(f"s_sub_u32 {S('t0')}, {S('t0')}, {ka('NB')}")
+            self.i(f"s_or_b32 {S('t0')}, {S('t0')}, {S('n_sub')}")               # 0 <=> the middle block, as a heavy (first) item
+            self.i(f"s_cmp_eq_u32 {S('t0')}, 0")
+            self.i(f"s_cbranch_scc1 {lone}")
             self.i(f"s_xor_b32 {S('n_sub')}, {S('n_sub')}, 1")
             self.i(f"s_cmp_eq_u32 {S('n_sub')}, 0")
             self.i(f"s_cselect_b32 {S('t0')}, 1, 0")
             self.i(f"s_add_u32 {S('n_u')}, {S('n_u')}, {S('t0')}")
+            self.i(f"s_branch {ldone}")
+            self.lab(lone)
+            self.i(f"s_add_u32 {S('n_u')}, {S('n_u')}, 1")
+            self.lab(ldone)
         else:
             self.i(f"s_add_u32 {S('n_u')}, {S('n_u')}, 1")
         self.decode()

@@ -136,7 +136,7 @@ Variant pick(const pfa_fa3_args* a) {
         // D = 64: the tile loop is bound by the softmax's vector instructions (half the MFMA work under the same exponentials), where
         // two waves per SIMD (the 8-wave HIP kernel) overlap better than one: the persistent kernel only wins while every unit has a CU
         // of its own, i.e. no item seam (same box: C2 +3 %, 256 units +2 %; 384 units -9 %, 1024 units -8 %).  Selector 45 forces it.
-        const int64_t units = (int64_t)a->B * a->H * ((a->Sq + 255) / 256) / (causal ? 2 : 1);
+        const int64_t nbq = ((int64_t)a->Sq + 255) / 256, units = (int64_t)a->B * a->H * (causal ? (nbq + 1) / 2 : nbq);
         const bool take = a->D == 128 || var == 45 || units <= v.p4_grid;
         if (v.p4_grid > 0 && take) return v;   // (0: the code object did not load on this device -- fall through to the HIP kernels)
     }

@@ -112,15 +112,15 @@ bool fits_u32(int64_t x) { return x >= 0 && x <= 0xffffffffLL; }
 // multiple of 256 or Sk no multiple of 128 -- rows past the end are kept out by buffer descriptors, keys past Sk by a computed mask word)
 int p4_flavour(const pfa_fa3_args* a) {
     if (a->key_mask) return 1;
-    const bool whole = a->Sq % 256 == 0 && a->Sk % 128 == 0 && (!a->causal || (a->Sq / 256) % 2 == 0);
+    const bool whole = a->Sq % 256 == 0 && a->Sk % 128 == 0;
     return whole && !a->seqlens_k ? 0 : 2;       // (per-batch key counts: the ragged kernels' length word, and tile counts cut to the length)
 }
 
 // Shapes the persistent kernel takes (everything else stays on the HIP kernels): D = 128 or 64; the fast variant (one P operand, 16-bit
 // store) or the parity variant (split P AND fp32 store); no element mask; Sq >= 128 and Sk >= 193 of any length (ragged: *_kl_*); a
 // [B, Sk] key mask with contiguous rows on whole blocks / tile pairs (*_km_*: the kernel reads the bytes itself); seqlens_k without the
-// causal mask (an item's tile count is cut to its batch's keys); under the causal mask Sq == Sk and an even number of Q blocks (units
-// are heavy + light block pairs).
+// causal mask (an item's tile count is cut to its batch's keys); under the causal mask Sq == Sk (units are heavy + light block pairs,
+// with an odd block count the middle block is a unit of its own).
 bool p4_eligible(const pfa_fa3_args* a) {
     const bool split = (a->flags & PFA_FLAG_SPLIT_P) != 0, out32 = a->dtype_out == PFA_DTYPE_FP32;
     if ((a->D != 128 && a->D != 64) || split != out32) return false;
@@ -130,7 +130,7 @@ bool p4_eligible(const pfa_fa3_args* a) {
     const int64_t NBq = ((int64_t)a->Sq + 255) / 256;
     if (a->key_mask && (a->Sq % 256 != 0 || a->Sk % 128 != 0)) return false;          // (the mask bytes of a tile past Sk do not exist)
     if (a->Sq < 128 || a->Sk < 193) return false;      // at least half a Q block of rows; at least four key tiles, the first three of them whole
-    if (a->causal && (a->Sq != a->Sk || NBq % 2 != 0)) return false;                   // units are (heavy, light) block pairs
+    if (a->causal && a->Sq != a->Sk) return false;      // (units are (heavy, light) block pairs; an odd block count leaves the middle block alone)
     const int64_t st[] = {a->q_stride_b, a->q_stride_h, a->q_stride_s, a->k_stride_b, a->k_stride_h, a->k_stride_s,
                           a->v_stride_b, a->v_stride_h, a->v_stride_s};
     for (int64_t s : st)
@@ -142,7 +142,7 @@ bool p4_eligible(const pfa_fa3_args* a) {
     if (256 * a->q_stride_s * 2 > 0x7fffffffLL || 256 * a->o_stride_s * osz > 0x7fffffffLL) return false;
     if ((a->o_stride_s * osz) % 16 != 0 || (a->o_stride_h * osz) % 16 != 0 || (a->o_stride_b * osz) % 16 != 0 ||
         (reinterpret_cast<uintptr_t>(a->o) & 15u)) return false;                                       // 16-byte row stores
-    const int64_t BH = (int64_t)a->B * a->H, NB = NBq, NU = a->causal ? NB / 2 : NB;
+    const int64_t BH = (int64_t)a->B * a->H, NB = NBq, NU = a->causal ? (NB + 1) / 2 : NB;
     if (BH * NU > (1ll << 24) || BH * a->H >= (1ll << 32)) return false;                                 // multiply-high ranges
     return true;
 }
@@ -170,7 +170,7 @@ int p4_launch(const pfa_fa3_args* a, void* stream, int* hip_err) {
     p.o_sb = (uint32_t)(a->o_stride_b * osz); p.o_sh = (uint32_t)(a->o_stride_h * osz); p.o_ss = (uint32_t)(a->o_stride_s * osz);
     p.H = (uint32_t)a->H; p.Sq = (uint32_t)a->Sq; p.Sk = (uint32_t)a->Sk;
     p.NB = (uint32_t)((a->Sq + 255) / 256);
-    p.NU = a->causal ? p.NB / 2 : p.NB;
+    p.NU = a->causal ? (p.NB + 1) / 2 : p.NB;
     p.magic_NU = magic(p.NU); p.magic_H = magic(p.H);
     p.kv_group = a->kv_group > 1 ? (uint32_t)a->kv_group : 1u;
     p.magic_G = magic(p.kv_group);

@@ -380,6 +380,8 @@ P4_CASES = [
     (1, 8, 256, 256, False, 8),         # a single 4-tile item
     (2, 4, 1024, 1024, True, 4),
     (1, 3, 512, 512, True, 3),          # heads not a multiple of 8: linear workgroup -> unit map
+    (2, 8, 768, 768, True, 8),          # an odd number of Q blocks under the causal mask: (2, 0) and the middle block alone
+    (3, 5, 256, 256, True, 5),          # a single causal block
     (3, 5, 768, 640, False, 5),         # Sq != Sk
     (1, 16, 2048, 2048, True, 4),       # grouped-query heads
     (2, 16, 1024, 2304, False, 2),      # cross attention, long keys, GQA
@@ -477,7 +479,8 @@ def test_p4_key_mask_kernels_against_the_oracle(case, kind, dtype):
 
 
 @pytest.mark.parametrize("case", [(1, 8, 300, 300, False, 128), (2, 4, 257, 193, False, 128), (1, 8, 1000, 1000, True, 128), (2, 3, 512, 1000, False, 128),
-                                  (2, 8, 1024, 1025, False, 128), (1, 8, 129, 2000, False, 128), (2, 4, 1500, 1500, True, 64), (3, 5, 700, 640, False, 64)])
+                                  (2, 8, 1024, 1025, False, 128), (1, 8, 129, 2000, False, 128), (2, 4, 1500, 1500, True, 64), (3, 5, 700, 640, False, 64),
+                                  (1, 16, 700, 700, True, 128), (9, 32, 200, 200, True, 128), (3, 8, 1281, 1281, True, 64)])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_p4_ragged_kernels_against_the_oracle(case, dtype):
     """Sq no multiple of 256 / Sk no multiple of 128 on the persistent schedule (fa3_fwd_p4_*_kl_*): against the oracle, against the
@@ -583,10 +586,11 @@ def test_p4_kernel_reads_fused_qkv_views_and_is_the_default_for_long_aligned_pro
     # ragged lengths: the *_kl_* kernels (rows past the end kept out by the buffer descriptors, keys past Sk by a computed mask word)
     q2, k2, v2 = (t[:, :, :2000] for t in (q, k, v))
     assert _capi.describe(ops.build_args(q2, k2, v2, out[:, :, :2000], causal=False)[0])[0] == "fa3_fwd_p4_bf16_d128_full_kl_o16"
-    # not eligible -> the HIP kernels: short key sequences, an odd number of Q blocks under the causal mask, element masks, seqlens, fp32 store with one P
+    q3, k3, v3 = (t[:, :, :700] for t in (q, k, v))            # an odd number of Q blocks under the causal mask: the middle block is a unit of its own
+    assert _capi.describe(ops.build_args(q3, k3, v3, out[:, :, :700], causal=True)[0])[0] == "fa3_fwd_p4_bf16_d128_causal_kl_o16"
+    # not eligible -> the HIP kernels: short key sequences, Sq != Sk under the causal mask, element masks, causal seqlens, fp32 store with one P
     assert "p4" not in _capi.describe(ops.build_args(q2, k2[:, :, :192], v2[:, :, :192], out[:, :, :2000], causal=False)[0])[0]
-    q3, k3, v3 = (t[:, :, :700] for t in (q, k, v))
-    assert "p4" not in _capi.describe(ops.build_args(q3, k3, v3, out[:, :, :700], causal=True)[0])[0]
+    assert "p4" not in _capi.describe(ops.build_args(q3, k2, v2, out[:, :, :700], causal=True)[0])[0]
     o32 = torch.empty(B, S, H, D, device="cuda:0", dtype=torch.float32).permute(0, 2, 1, 3)
     assert _capi.describe(ops.build_args(q, k, v, o32, causal=False, split_p=True)[0])[0] == "fa3_fwd_p4_bf16_d128_full_splitp_o32"
     assert "p4" not in _capi.describe(ops.build_args(q, k, v, o32, causal=False, split_p=False)[0])[0]      # fp32 store, one P: HIP kernel
