@@ -610,7 +610,12 @@ class Gen:
         if self.klen and not self.causal:
             self.i(f"s_mov_b32 {ka('pad')}, {S('L_n')}")                 # keys left from tile j+2 on
         self.lab(l1)
-        if self.kmask:
+        if self.kmask and not self.causal:                              # (only the lanes whose keys the batch has: nothing is read past a mask row)
+            self.len_word(0, dst=S('t2'), left=S('n_sub'))
+            self.i(f"s_mov_b64 exec, {S('t2')}")
+            self.emit(self.mask_load())
+            self.i("s_mov_b64 exec, -1")
+        elif self.kmask:
             self.emit(self.mask_load())                                 # the bytes of tile j+2 (its K pieces go to slot p in this iteration)
         if self.klen and not self.causal:
             self.len_word(p)                                            # the word of tile j+2 from the keys left
@@ -904,7 +909,7 @@ class Gen:
         self.i(f"s_add_u32 {lo}, {lo}, {ka('q')}")
         self.i(f"s_addc_u32 {hi}, {hi}, {ka('q', hi=True)}")
         self.i(f"s_and_b32 {hi}, {hi}, 0xffff")
-        if self.klen:                          # records = the block's rows that exist
+        if self.klen or self.kmask:            # records = the block's rows that exist
             self.block_records(S('qsrd_n', 2), S('n_qblk'), 'q_ss', self.RB, t3)
         if (self.klen or self.kmask) and not self.causal:
             # seqlens_k (kernarg dwords 40 / 41, null = none): the item's keys L = clamp(seqlens_k[b], 0, Sk) and its tile count cut to them
@@ -969,7 +974,7 @@ class Gen:
         self.i(f"s_add_u32 {S('lsrd', 0)}, {ka('lse')}, {t3}")
         self.i(f"s_addc_u32 {S('lsrd', 1)}, {ka('lse', hi=True)}, {th}")
         self.i(f"s_and_b32 {S('lsrd', 1)}, {S('lsrd', 1)}, 0xffff")
-        if self.klen:                          # both end with the block's last existing row
+        if self.klen or self.kmask:            # both end with the block's last existing row
             self.block_records(S('osrd', 2), S('n_qblk'), 'o_ss', self.RB * (2 if self.out32 else 1), t3)
             self.block_records(S('lsrd', 2), S('n_qblk'), 4, 4, t3)
 

@@ -428,7 +428,8 @@ def test_p4_kernel_against_the_oracle_and_the_8_wave_kernel(case, dtype):
     assert err <= PARITY_TOL and float((p45 - p44).abs().max()) <= 3e-5, (case, dtype, err)
 
 
-@pytest.mark.parametrize("case", [(2, 8, 512, 512, True, 128), (3, 4, 256, 384, False, 128), (2, 4, 1024, 768, False, 64), (2, 8, 1024, 1024, True, 64)])
+@pytest.mark.parametrize("case", [(2, 8, 512, 512, True, 128), (3, 4, 256, 384, False, 128), (2, 4, 1024, 768, False, 64), (2, 8, 1024, 1024, True, 64),
+                                  (2, 8, 300, 300, False, 128), (4, 4, 1024, 1025, False, 64)])     # the last two: ragged Sq / Sk under a key mask
 @pytest.mark.parametrize("kind", ["padding", "random", "empty_row"])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_p4_key_mask_kernels_against_the_oracle(case, kind, dtype):
@@ -456,7 +457,7 @@ def test_p4_key_mask_kernels_against_the_oracle(case, kind, dtype):
     o44, l44 = ops.fa3_forward(qd, kd, vd, causal=causal, key_mask=kmd, out_dtype=torch.float32, return_lse=True, _variant=44)
     torch.cuda.synchronize()
     name = _capi.describe(ops.build_args(qd, kd, vd, o16, causal=causal, key_mask=kmd)[0])[0]
-    small = D == 64 and B * H * (Sq // 256) // (2 if causal else 1) > 256
+    small = D == 64 and B * H * ((Sq + 255) // 256) // (2 if causal else 1) > 256
     assert small or name.startswith(f"fa3_fwd_p4_{dtype}_d{D}_{'causal' if causal else 'full'}_km_o16"), name      # picked without a selector
     mask4 = km.view(B, 1, 1, Sk).expand(B, 1, Sq, Sk)
     if causal:
