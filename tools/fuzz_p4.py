@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Soak of the persistent assembly forward: random ELIGIBLE problems (D 64 / 128, causal or not, optional [B,Sk] key mask of three kinds,
-grouped-query heads, operands as strided views of a fused buffer, 1 .. many items per workgroup) -- selector 45 against the 8-wave
+"""Soak of the persistent assembly forward: random ELIGIBLE problems (D 64 / 128, causal or not, whole or ragged Sq / Sk, optional
+[B,Sk] key mask of three kinds, optional seqlens_k, grouped-query heads, operands as strided views of a fused buffer, 1 .. many items
+per workgroup) -- selector 45 against the 8-wave
 HIP kernel (44): parity variant (fp32 store + split P) to 3e-5, fast variant to its store + P rounding, LSE to 3e-5, -inf rows alike.
     timeout -k 10 600 python3 tools/fuzz_p4.py [N] [seed]"""
 import os, random, sys
@@ -17,9 +18,16 @@ for it in range(N):
     B, H = rnd.choice([(1, 1), (1, 8), (2, 3), (1, 24), (4, 8), (1, 40), (7, 5), (2, 64)])
     g = rnd.choice([x for x in (1, 2, 4, 8) if H % x == 0])
     if causal:
-        Sq = Sk = 512 * rnd.randint(1, 5)
+        Sq = Sk = 256 * rnd.randint(1, 9)
     else:
         Sq, Sk = 256 * rnd.randint(1, 7), 128 * rnd.randint(2, 14)
+    ragged = rnd.random() < 0.4
+    if ragged:
+        Sq = max(128, Sq - rnd.randint(1, 255))
+        Sk = Sq if causal else max(193, Sk - rnd.randint(1, 127))
+        Sq = Sk if causal else Sq
+        Sk = max(Sk, 193)
+        Sq = Sk if causal else Sq
     dtype = rnd.choice(["bf16", "fp16"])
     tdt = torch.bfloat16 if dtype == "bf16" else torch.float16
     gen = torch.Generator(device=dev).manual_seed(90000 + it)
@@ -30,21 +38,24 @@ for it in range(N):
         q = torch.randn(B, Sq, H, D, device=dev, generator=gen).to(tdt).permute(0, 2, 1, 3)
         k, v = (torch.randn(B, Sk, H // g, D, device=dev, generator=gen).to(tdt).permute(0, 2, 1, 3) for _ in range(2))
     kind = rnd.choice(["none", "none", "pad", "rand", "row0"])
+    if causal and ragged:
+        kind = "none"                                        # (ragged key masks under the causal mask stay on the HIP kernels)
+    lens = [rnd.choice([0, 1, Sk, rnd.randint(0, Sk)]) for _ in range(B)] if (not causal and rnd.random() < 0.3) else None
     km = None
     if kind == "pad":
-        lens = torch.randint(1, Sk + 1, (B,), generator=gen, device=dev)
-        km = torch.arange(Sk, device=dev)[None, :] < lens[:, None]
+        plen = torch.randint(1, Sk + 1, (B,), generator=gen, device=dev)
+        km = torch.arange(Sk, device=dev)[None, :] < plen[:, None]
     elif kind in ("rand", "row0"):
         km = torch.rand(B, Sk, generator=gen, device=dev) < 0.75
         if kind == "row0":
             km[rnd.randrange(B)] = False
-    kw = dict(causal=causal, key_mask=km, return_lse=True)
+    kw = dict(causal=causal, key_mask=km, seqlens_k=lens, return_lse=True)
     p45, l45 = ops.fa3_forward(q, k, v, out_dtype=torch.float32, _variant=45, **kw)
     p44, l44 = ops.fa3_forward(q, k, v, out_dtype=torch.float32, _variant=44, **kw)
-    f45 = ops.fa3_forward(q, k, v, causal=causal, key_mask=km, _variant=45)[0]
+    f45 = ops.fa3_forward(q, k, v, causal=causal, key_mask=km, seqlens_k=lens, _variant=45)[0]
     torch.cuda.synchronize()
-    tag = (it, D, B, H, g, Sq, Sk, causal, kind, dtype)
-    name = _capi.describe(ops.build_args(q, k, v, f45, causal=causal, key_mask=km, variant=45)[0])[0]
+    tag = (it, D, B, H, g, Sq, Sk, causal, kind, lens, dtype)
+    name = _capi.describe(ops.build_args(q, k, v, f45, causal=causal, key_mask=km, seqlens_k=lens, variant=45)[0])[0]
     assert name.startswith("fa3_fwd_p4_") and (("_km_" in name) == (km is not None)), (tag, name)
     assert bool(torch.isfinite(p45).all()) and bool(torch.isfinite(f45.float()).all()), tag
     d = float((p45 - p44).abs().max())
