@@ -175,6 +175,10 @@ class Gen:
         # needed under the causal mask: a valid row never looks that far).
         self.klen = klen
         assert not (kmask and klen)
+        # key-mask kernels: the keys left from the tile whose mask bytes are fetched next ride in a register the flavour does not use
+        # otherwise -- the causal kernels' sub-item flag without the causal mask, the seqlens register (non-causal only) with it --
+        # and start an item at the keys its batch has (seqlens_k; Sk without it, and always under the causal mask)
+        self.kleft, self.kleft0 = (S('L_n'), ka('Sk')) if causal else (S('n_sub'), S('L_n'))
         self.mwords = kmask or (klen and not causal)
         assert not (kmask and STAMP), "the key-mask kernels keep their mask words where the stamps keep their clock (s[58:59], the dbg kernarg)"
         assert D in (64, 128)
@@ -315,12 +319,12 @@ class Gen:
 
     def km_len_and(self, i):
         """key-mask kernels without the causal mask: the word just made from the mask bytes AND the keys its batch has (seqlens_k;
-        Sk without it).  The keys left ride in `n_sub` (the causal kernels' sub-item flag: unused here)."""
-        if not (self.kmask and not self.causal):
+        Sk without it, and under the causal mask).  The keys left: self.kleft."""
+        if not self.kmask:
             return
-        self.len_word(i, dst=S('t2'), left=S('n_sub'))
+        self.len_word(i, dst=S('t2'), left=self.kleft)
         self.i(f"s_and_b64 {self.MK(i)}, {self.MK(i)}, {S('t2')}")
-        self.i(f"s_sub_u32 {S('n_sub')}, {S('n_sub')}, 64")
+        self.i(f"s_sub_u32 {self.kleft}, {self.kleft}, 64")
 
     def mask_load(self, n=0):
         v = vr(self.KM_V[n])
@@ -605,18 +609,15 @@ class Gen:
         self.i(f"s_mov_b32 {S('krem')}, {S('nt_n')}")
         if self.kmask:                                                  # ... and so are its mask bytes: row n_b
             self.i(f"s_mul_i32 {ka('pad')}, {S('n_b')}, {ka('Sk')}")
-            if not self.causal:
-                self.i(f"s_mov_b32 {S('n_sub')}, {S('L_n')}")             # ... and the keys its batch has
+            self.i(f"s_mov_b32 {self.kleft}, {self.kleft0}")             # ... and the keys its batch has
         if self.klen and not self.causal:
             self.i(f"s_mov_b32 {ka('pad')}, {S('L_n')}")                 # keys left from tile j+2 on
         self.lab(l1)
-        if self.kmask and not self.causal:                              # (only the lanes whose keys the batch has: nothing is read past a mask row)
-            self.len_word(0, dst=S('t2'), left=S('n_sub'))
+        if self.kmask:                                                  # the bytes of tile j+2 (its K pieces go to slot p in this iteration),
+            self.len_word(0, dst=S('t2'), left=self.kleft)              # only the lanes whose keys the batch has: nothing is read past a mask row
             self.i(f"s_mov_b64 exec, {S('t2')}")
             self.emit(self.mask_load())
             self.i("s_mov_b64 exec, -1")
-        elif self.kmask:
-            self.emit(self.mask_load())                                 # the bytes of tile j+2 (its K pieces go to slot p in this iteration)
         if self.klen and not self.causal:
             self.len_word(p)                                            # the word of tile j+2 from the keys left
         self.i(f"s_cmp_lg_u32 {S('vrem')}, 0")
@@ -1559,10 +1560,9 @@ class Gen:
         if self.kmask:
             self.i(self.mask_word(0, 0))
             self.i(self.mask_word(1, 1))
-            if not self.causal:
-                self.i(f"s_mov_b32 {S('n_sub')}, {S('L_n')}")
-                self.km_len_and(0)
-                self.km_len_and(1)
+            self.i(f"s_mov_b32 {self.kleft}, {self.kleft0}")
+            self.km_len_and(0)
+            self.km_len_and(1)
         self.i("s_barrier")
         litem = f".L{n}_item"
         self.lab(litem)
@@ -1579,7 +1579,8 @@ class Gen:
             # pieces left to request (qrem == 0), no stream switch in either iteration (krem >= 2) and, under the causal mask, FULL
             # bodies without a diagonal tile (wrem = krem - 2 + wave >= 3).  A lean iteration issues the same DMA pieces and meets the
             # same barriers as a generic one, so every wave decides for itself.  (17 scalar instructions a tile were ~9 % of it.)
-            self.i(f"s_cmp_lt_u32 {S('krem')}, {5 if self.causal else (4 if (self.klen or self.kmask) else 2)}")      # (lengths: tiles j+2, j+3 whole too)
+            # (lengths: tiles j+2, j+3 whole too; a causal item's last block may run three tiles past the keys: its mask bytes)
+            self.i(f"s_cmp_lt_u32 {S('krem')}, {(7 if self.kmask else 5) if self.causal else (4 if (self.klen or self.kmask) else 2)}")
             self.i(f"s_cbranch_scc1 {lgen}")
             self.i(f"s_cmp_lg_u32 {S('qrem')}, 0")
             self.i(f"s_cbranch_scc1 {lgen}")
@@ -1597,8 +1598,8 @@ class Gen:
                 self.i("s_barrier")
             for c in ("krem", "vrem", "wrem", "irem"):
                 self.i(f"s_sub_u32 {S(c)}, {S(c)}, 2")
-            if self.kmask and not self.causal:      # (their words need no length: all keys exist)
-                self.i(f"s_sub_u32 {S('n_sub')}, {S('n_sub')}, 128")
+            if self.kmask:                          # (their words need no length: all keys exist)
+                self.i(f"s_sub_u32 {self.kleft}, {self.kleft}, 128")
             if self.klen and not self.causal:       # the words of tiles j+2, j+3 (all keys exist), the keys left behind them
                 self.i(f"s_mov_b64 {self.MK(0)}, -1")
                 self.i(f"s_mov_b64 {self.MK(1)}, -1")

@@ -128,7 +128,6 @@ bool p4_eligible(const pfa_fa3_args* a) {
     if (a->mask || (a->seqlens_k && a->causal)) return false;      // (seqlens_k under the causal mask: the HIP kernels)
     if (a->key_mask && (a->key_mask_stride_b != a->Sk || (int64_t)a->B * a->Sk > 0x7fffffffLL)) return false;   // its 32-bit running byte offset
     const int64_t NBq = ((int64_t)a->Sq + 255) / 256;
-    if (a->key_mask && a->causal && (a->Sq % 256 != 0 || a->Sk % 128 != 0)) return false;   // (causal key-mask kernels carry no count of the keys left: whole tiles only)
     if (a->Sq < 128 || a->Sk < 193) return false;      // at least half a Q block of rows; at least four key tiles, the first three of them whole
     if (a->causal && a->Sq != a->Sk) return false;      // (units are (heavy, light) block pairs; an odd block count leaves the middle block alone)
     const int64_t st[] = {a->q_stride_b, a->q_stride_h, a->q_stride_s, a->k_stride_b, a->k_stride_h, a->k_stride_s,

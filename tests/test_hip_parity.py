@@ -429,7 +429,7 @@ def test_p4_kernel_against_the_oracle_and_the_8_wave_kernel(case, dtype):
 
 
 @pytest.mark.parametrize("case", [(2, 8, 512, 512, True, 128), (3, 4, 256, 384, False, 128), (2, 4, 1024, 768, False, 64), (2, 8, 1024, 1024, True, 64),
-                                  (2, 8, 300, 300, False, 128), (4, 4, 1024, 1025, False, 64)])     # the last two: ragged Sq / Sk under a key mask
+                                  (2, 8, 300, 300, False, 128), (4, 4, 1024, 1025, False, 64), (3, 4, 769, 769, True, 128)])     # the last three: ragged Sq / Sk under a key mask
 @pytest.mark.parametrize("kind", ["padding", "random", "empty_row"])
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
 def test_p4_key_mask_kernels_against_the_oracle(case, kind, dtype):

@@ -34,7 +34,8 @@ bad = 0
 for (B, H, Sq, Sk, causal) in [(2, 8, 512, 512, True), (3, 4, 256, 384, False), (2, 8, 1024, 1024, False), (4, 8, 512, 512, True), (5, 3, 768, 640, False),
                                (2, 16, 2048, 2048, True),
                                # ragged shapes (no causal mask): per-item descriptor records, byte loads limited to the lanes whose keys exist
-                               (2, 8, 300, 300, False), (3, 4, 257, 193, False), (2, 8, 1000, 1000, False), (1, 8, 129, 3001, False), (4, 4, 1024, 1025, False)]:
+                               (2, 8, 300, 300, False), (3, 4, 257, 193, False), (2, 8, 1000, 1000, False), (1, 8, 129, 3001, False), (4, 4, 1024, 1025, False),
+                               (2, 8, 1000, 1000, True), (3, 4, 769, 769, True), (1, 16, 2000, 2000, True), (2, 8, 200, 200, True)]:
     for kind in ("pad", "rand", "row0"):
         g = torch.Generator(device=dev).manual_seed(B * 1000 + H * 10 + Sq + len(kind))
         q = torch.randn(B, Sq, H, D, device=dev, generator=g).to(dt).permute(0, 2, 1, 3)
