@@ -3,10 +3,10 @@
 
     python3 gen_fa3_fwd_p4.py > build/fa3_fwd_p4.s        (the Makefile assembles it into the code object that libpfa_hip.so embeds)
 
-Replaces the reference's tile loop (core/flash_attention_3.py:207-260) on the shapes pfa_capi.hip routes here (D = 128, Sq a
-multiple of 256 [512 under a causal mask], Sk a multiple of 128, no mask, no seqlens): the same math, LDS images and MFMA operand
-maps as fa3_fwd_w4_kernel.h (4 waves x 64 query rows, one wave per SIMD, S^T = K Q^T and O^T += V^T P^T on
-v_mfma_f32_32x32x16, online softmax with defer-max), but
+Replaces the reference's tile loop (core/flash_attention_3.py:207-260) on the shapes pfa_capi.hip routes here (pfa_p4.hip
+p4_eligible: D = 128 or 64, Sq >= 128, Sk >= 193, no element mask): the same math, LDS images and MFMA operand maps as
+fa3_fwd_w4_kernel.h (4 waves x 64 query rows, one wave per SIMD, S^T = K Q^T and O^T += V^T P^T on v_mfma_f32_32x32x16, online
+softmax with defer-max), but
 
   * PERSISTENT: one workgroup per CU walks a static list of (head, Q block) items; the K/V LDS-DMA ring keeps running across
     the item seam (the last two iterations of an item already fetch tiles 0 / 1 of the next one), the next item's Q rows are
@@ -17,11 +17,15 @@ v_mfma_f32_32x32x16, online softmax with defer-max), but
     pairs (8 s_waitcnt per phase instead of 16), one M0 write per four DMA pieces (a wave's pieces are contiguous in LDS, the
     piece index rides in the instruction's immediate offset), the tile offset in the load's scalar offset (no VALU), no
     compiler-inserted s_nop / v_mov; the rare paths (O rescale, diagonal mask, a wave's last tile) sit out of line.
+  * the tile loop exists twice (generic iteration / lean double iteration far from an item's ends), an item's last iteration runs on
+    its successor's Q fragments (body_seam), and three flavours share the code: plain (whole blocks and tiles), *_km_* ([B, Sk] key
+    mask: the waves read the mask bytes themselves) and *_kl_* (ragged lengths, seqlens_k); all of that is described where it is
+    emitted (kernel(), body_seam(), mask_keys(), Gen.__init__).
 
-Register plan (per wave, 512 registers):
-    a[0:63] O of strip A, a[64:127] O of strip B, a[128:159] / a[160:191] the Q fragments of A / B
+Register plan (per wave, 512 registers; D = 128 -- D = 64 halves O and Q):
+    a[0:63] O of strip A, a[64:127] O of strip B, a[128:159] / a[160:191] the Q fragments of A / B, a[192:255] the K / V^T fragment rings
     v[16:143] S, double buffered: buf0 A, buf0 B, buf1 A, buf1 B (32 each: key block 0, key block 1)
-    v[144:175] P (packed bf16) of A / B, v[176:191] K fragment ring, v[192:207] V^T fragment ring, v[208:] addresses and state
+    v[144:175] P (packed 16-bit) of A / B, v[176:207] the low halves of a split P, v[208:] addresses and state, v[0:15] scratch
 """
 import os
 import sys
