@@ -95,6 +95,7 @@ def PDL(X, i):              # split P: the low halves (the VGPRs the 4-deep frag
 
 PKADD = int(os.environ.get("P4_PKADD", "0"))        # EXPERIMENT, off: row sums as v_pk_add_f32 on register pairs (32 instead of 64 instructions a tile) ran 5-7 % SLOWER
 SEAM = int(os.environ.get("P4_SEAM", "1"))          # the item seam as one more FULL iteration (kernel(), body_seam): 0 = LAST body, epilogue, prologue one after the other
+WAITN = int(os.environ.get("P4_WAITN", "2"))        # LDS fragments waited for at a time (2: 8 s_waitcnt per phase; 4: 4)
 LEAN = int(os.environ.get("P4_LEAN", "1"))          # the tile loop's lean path (kernel()): 0 = every iteration carries the full bookkeeping
 RING = int(os.environ.get("P4_RING", "8"))          # K / V^T fragment rings: 4 (VGPRs) or 8 (the spare accumulator registers a[192:255])
 KFR = lambda i: (192 + 4 * (i % 8)) if RING == 8 else (176 + 4 * (i % 4))
@@ -535,8 +536,8 @@ class Gen:
         for hs in range(ngaps):
             i, X = hs // 2, 'AB'[hs % 2]
             mark = len(self.L)
-            if hs % 2 == 0 and i % 2 == 0:
-                w = lg.need([('k', i), ('k', i + 1)])
+            if hs % 2 == 0 and i % WAITN == 0:
+                w = lg.need([('k', i + x) for x in range(WAITN)])
                 if w:
                     self.i(w)
             self.i(self.qk_mfma(nb, X, i))
@@ -572,8 +573,8 @@ class Gen:
         for idx in range(NF):
             for n, (X, lo) in enumerate(passes):
                 mark = len(self.L)
-                if n == 0 and idx % 2 == 0:
-                    w = lg.need([('v', idx, 1), ('v', idx + 1, 1)])
+                if n == 0 and idx % WAITN == 0:
+                    w = lg.need([('v', idx + x, 1) for x in range(WAITN)])
                     if w:
                         self.i(w)
                 self.i(self.pv_mfma(X, idx, lo))
