@@ -391,7 +391,7 @@ class Gen:
     # softmax FINISH of strip X on buffer `buf`: the exponentials of key block 1 and all sixteen P dwords, as an in-order stream.
     # The v_fma of element e+1 is issued ahead of the v_exp of element e and no two dependent adds are adjacent (a dependent VALU
     # pair costs issue stalls: SQ_WAIT_INST_ANY was 15 % of the wave's cycles with fma -> exp and add -> add back to back).
-    def finish_stream(self, X, buf, ps1=V_PS1):
+    def finish_stream(self, X, buf, ps1=V_PS1, tmp=(V_T[2], V_T[3])):
         c1 = lambda k: vr(SBUF(buf, X, 1, k))
         c0 = lambda k: vr(SBUF(buf, X, 0, k))
         mc, ps0, l = vr(STV(X, 'mc')), vr(STV(X, 'ps0')), vr(STV(X, 'l'))
@@ -401,7 +401,7 @@ class Gen:
             """P dword i = the pair (x0, x1) in 16 bits; split P: also the pair of what the rounding left behind"""
             r = [f"{self.cvt} {vr(PD(X, i))}, {x0}, {x1}"]
             if self.split:
-                t0, t1, hi = vr(V_T[2]), vr(V_T[3]), vr(PD(X, i))
+                t0, t1, hi = vr(tmp[0]), vr(tmp[1]), vr(PD(X, i))
                 if self.dt == "bf16":
                     r += [f"v_lshlrev_b32 {t0}, 16, {hi}", f"v_and_b32 {t1}, 0xffff0000, {hi}"]
                 else:
@@ -751,8 +751,8 @@ class Gen:
         self.stamp(2)
         self.abl_on = True
         # ---- phase A: the finish of both strips as ONE in-order stream, sliced evenly over the gaps around their fixed content
-        if ILV and not self.split:             # the two strips' streams interleaved: twice the distance between dependent instructions (-0.7 % cycles)
-            fin = self.interleave(self.finish_stream('A', p), self.finish_stream('B', p, ps1=V_MX))
+        if ILV:                                # the two strips' streams interleaved: twice the distance between dependent instructions (-0.7 % cycles)
+            fin = self.interleave(self.finish_stream('A', p), self.finish_stream('B', p, ps1=V_MX, tmp=(V_E[6], V_E[7])))
             fin = [f"v_mov_b32 {vr(V_MX)}, 0"] + fin
         else:
             fin = self.finish_stream('A', p) + self.finish_stream('B', p)
@@ -779,7 +779,7 @@ class Gen:
             self.i(f"s_branch {lr}")
             self.out_of_line(False)
         # ---- phase B: the start of both strips, same treatment
-        if ILV and not self.split:
+        if ILV:
             sta = self.interleave(self.start_stream('A', 1 - p), self.start_stream('B', 1 - p, alt=True))
         else:
             sta = self.start_stream('A', 1 - p) + self.start_stream('B', 1 - p)
