@@ -48,7 +48,7 @@ MFMA_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, 
 # per the gfx950 wide-load correction of MI355X_MICROARCH.md section HBM, + WRITE_SIZE).  Not measurable from inside
 # this process, so the committed profile is quoted, keyed by workload; null for anything not profiled.
 PMC_TRAFFIC_BYTES = {
-    "C3": (369.8e6, "profiles/r02_C3_rocprof_summary.md: FETCH_SIZE 152123 KB x 2 + WRITE_SIZE 65536 KB (1.38 x the algorithmic 268.4 MB)"),
+    "C3": (369.5e6, "profiles/r02_C3_rocprof_summary.md: FETCH_SIZE 151999 KB x 2 + WRITE_SIZE 65536 KB (1.38 x the algorithmic 268.4 MB)"),
 }
 
 WORKLOADS = {
