@@ -31,7 +31,6 @@ for name in (sys.argv[1:] or ["C3", "C4"]):
         per = [wall[x::nx].mean().item() for x in range(nx)]
         print("   wall per wave by workgroup % 8 (= XCD): " + " ".join(f"{v:.1f}" for v in per) + " us;  by wave: " +
               " ".join(f"{wall[:, w].mean().item():.1f}" for w in range(4)))
-        start = acc[..., 11 - 1 + 0]                          # (bucket 10 = total cycles; start ticks are not kept)
         continue
     print(f"{name}: FULL iterations {int(nfull)}, items {int(nitems)} (per workgroup-wave)")
     print(f"  per FULL iteration: QK^T phase {acc[..., 0].sum() / nfull:7.0f}   PV phase {acc[..., 1].sum() / nfull:7.0f} cycles")
