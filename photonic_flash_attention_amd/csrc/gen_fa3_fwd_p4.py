@@ -127,7 +127,6 @@ V_T = [250, 251, 252, 253]
 V_TA = 254            # causal: r + 1 - 4h (element-mask threshold of the diagonal tile, see mask_diag)
 V_LANE = 255
 V_E = list(range(0, 16))   # prologue / epilogue / rescale scratch (v0 = workitem id at entry)
-import os
 STAMP = int(os.environ.get("P4_STAMP", "0"))      # 1: every phase; 2: one stamp per iteration only (buckets 0 / 1 stay empty); 3: kernel totals only (lean loop and pipelined seam stay on)
 ABL = os.environ.get("P4_ABL", "")                                         # timing-only ablations, see dma_plan
 DMA_PRICE = int(os.environ.get("P4_DMA_PRICE", "30"))                      # issue cycles budgeted for one LDS-DMA piece
