@@ -1,7 +1,8 @@
 /*
  * pfa_hip.h -- C ABI of libpfa_hip.so: the MI355X (gfx950) Flash-Attention forward (and backward) that
  * replaces the body of the reference's electronic attention core.
- * ABI history: v1 forward; v2 general masks + weights; v3 backward; v4 grouped-query heads (kv_group).
+ * ABI history: v1 forward; v2 general masks + weights; v3 backward; v4 grouped-query heads (kv_group); v5 fp32 operands (exact
+ * fp32 kernels, forward and backward) and dense-branch attention dropout; v6 pfa_fa3_prepare, reserve_cus, pfa_probe_mfma.
  *
  * Reference seam (danieleschmidt/Photonic-Flash-Attention, all paths under
  * src/photonic_flash_attention/):
@@ -28,7 +29,9 @@
  *   - plain C, no C++/torch types; every pointer is a DEVICE pointer owned by the caller;
  *   - the library allocates nothing, frees nothing, keeps no reference after return;
  *   - asynchronous: work is enqueued on `stream` (a hipStream_t passed as void*), no implicit sync;
- *   - re-entrant and thread-safe: no mutable global state;
+ *   - re-entrant and thread-safe; the only process-wide state is one code-object handle per device (the assembly kernels'
+ *     hipModule_t), loaded once under a mutex by pfa_fa3_prepare / pfa_device_supported (or, failing that, by the first call)
+ *     and never changed afterwards;
  *   - returns PFA_OK (0) or a negative pfa_status; never aborts the process.
  */
 #ifndef PFA_HIP_H
@@ -41,7 +44,7 @@
 extern "C" {
 #endif
 
-#define PFA_ABI_VERSION 5
+#define PFA_ABI_VERSION 6
 
 typedef enum pfa_status {
     PFA_OK = 0,
@@ -68,8 +71,7 @@ typedef enum pfa_dtype {
 #define PFA_FLAG_NO_XCD_MAP 0x2u /* debugging: identity block->work mapping                                  */
 #define PFA_FLAG_VARIANT_MASK 0xff00u /* bits 8..15: kernel selector for tests / A-B runs.  0 = the library chooses; 43 = the 4-wave HIP kernel,
                                          44 = the 8-wave HIP kernel, 45 = the persistent 4-wave assembly kernel (each only where it applies;
-                                         otherwise the library's choice).  Anything else is PFA_ERR_FLAGS: schedule experiments and
-                                         timing-only ablations exist only in a development build (make DEV=1). */
+                                         otherwise the library's choice).  Anything else is PFA_ERR_FLAGS. */
 
 /*
  * One attention problem: O[b,i,h,:] = softmax_j(scale * <Q[b,i,h,:], K[b,j,h,:]> + mask) V[b,j,h,:]
@@ -118,7 +120,10 @@ typedef struct pfa_fa3_args {
      * 0 or 1 = one K/V head per query head.  H must be a multiple of kv_group.  Forward and weights only: the
      * backward wants expanded K/V (autograd then sums dK/dV over the group). */
     int32_t kv_group;
-    int32_t reserved0;          /* must be 0 */
+    /* ABI v6: CUs to leave free (0 = none).  The persistent forward holds one workgroup on every CU for the whole launch, so a
+     * kernel-based collective (RCCL) enqueued beside it only runs when it drains; a caller that overlaps such a collective passes
+     * the CUs it needs (the grid shrinks to n_cu - reserve_cus, a multiple of 8).  Copy-engine transfers need none. */
+    int32_t reserve_cus;
 
     /* ABI v5: attention dropout of the reference's dense branch (flash_attention_3.py:174-175: dropout(softmax(scores)) @ v).
      * drop_mask: keep-mask bytes [B][H][Sq][Sk] contiguous (non-zero = keep), drawn by the caller; kept weights are scaled by
@@ -137,6 +142,11 @@ const char* pfa_status_string(int status);
 
 /* 1 if HIP device `device_id` is a gfx950 part this library has code for, 0 if not, <0 on error. */
 int pfa_device_supported(int device_id);
+
+/* ABI v6: load the device's code objects NOW (idempotent, thread-safe): afterwards no call on that device loads a module, so a
+ * first pfa_fa3_fwd may sit inside a hipStreamBeginCapture region or a timed loop.  pfa_device_supported does the same.
+ * PFA_OK, or PFA_ERR_DEVICE (pfa_last_hip_error: why). */
+int pfa_fa3_prepare(int device_id);
 
 /* Last hipError_t seen by a failing call on this thread (0 = hipSuccess). */
 int pfa_last_hip_error(void);
@@ -222,6 +232,14 @@ int pfa_fa3_bwd(const pfa_fa3_bwd_args* a, void* stream);
  * would launch for `a` into buf (NUL terminated, truncated to n) and returns the number of workgroups.
  */
 int pfa_fa3_describe(const pfa_fa3_args* a, char* buf, size_t n);
+
+/*
+ * Measurement aid (bench.py, roofline.probe_tflops; not on the hot path): enqueue a bare v_mfma_f32_32x32x16_bf16 stream -- one wave
+ * per SIMD on every CU, A operands re-read from LDS as the forward's tile loop reads its K / V^T fragments, random operands taken from
+ * `random_64k` (64 KiB of device memory holding bf16 values) -- of `iters` x 64 MFMAs per wave.  `sink`: device scratch of
+ * 4 B x 256 x the number of CUs.  Returns the number of workgroups launched (> 0) or a pfa_status; *flops = the launch's flops.
+ */
+int pfa_probe_mfma(const void* random_64k, float* sink, int iters, int device_id, void* stream, double* flops);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ import os
 import threading
 from typing import Optional
 
-PFA_ABI_VERSION = 5
+PFA_ABI_VERSION = 6
 PFA_DTYPE_BF16, PFA_DTYPE_FP16, PFA_DTYPE_FP32 = 0, 1, 2
 PFA_FLAG_SPLIT_P = 0x1
 PFA_FLAG_NO_XCD_MAP = 0x2
@@ -24,7 +24,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "libpfa_hip.so")
 EXPORTS = (
     "pfa_abi_version", "pfa_status_string", "pfa_device_supported", "pfa_last_hip_error",
     "pfa_fa3_workspace_bytes", "pfa_fa3_check", "pfa_fa3_fwd", "pfa_fa3_describe", "pfa_fa3_weights",
-    "pfa_fa3_bwd", "pfa_fa3_bwd_workspace_bytes",
+    "pfa_fa3_bwd", "pfa_fa3_bwd_workspace_bytes", "pfa_fa3_prepare", "pfa_probe_mfma",
 )
 
 
@@ -46,7 +46,7 @@ class PfaFa3Args(C.Structure):
         ("mask", C.c_void_p),
         ("mask_stride_b", C.c_int64), ("mask_stride_h", C.c_int64), ("mask_stride_q", C.c_int64),
         ("mask_stride_k", C.c_int64),
-        ("kv_group", C.c_int32), ("reserved0", C.c_int32),
+        ("kv_group", C.c_int32), ("reserve_cus", C.c_int32),
         ("drop_mask", C.c_void_p), ("drop_scale", C.c_float), ("reserved1", C.c_int32),
     ]
 
@@ -111,6 +111,10 @@ def load(path: Optional[str] = None):
         lib.pfa_fa3_bwd_workspace_bytes.argtypes = [C.POINTER(PfaFa3BwdArgs)]
         lib.pfa_fa3_describe.restype = C.c_int
         lib.pfa_fa3_describe.argtypes = [C.POINTER(PfaFa3Args), C.c_char_p, C.c_size_t]
+        lib.pfa_fa3_prepare.restype = C.c_int
+        lib.pfa_fa3_prepare.argtypes = [C.c_int]
+        lib.pfa_probe_mfma.restype = C.c_int
+        lib.pfa_probe_mfma.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
         v = lib.pfa_abi_version()
         if v != PFA_ABI_VERSION:
             raise OSError(f"{p}: ABI version {v}, binding expects {PFA_ABI_VERSION}")

@@ -30,6 +30,21 @@ Register plan (per wave, 512 registers; D = 128 -- D = 64 halves O and Q):
 import os
 import sys
 
+
+# Experiment / diagnostic knobs (P4_*): read from the environment ONLY with P4_DEV=1 (tools/p4_variants.py builds such code objects for
+# same-process A/B runs and stamped diagnostics; they are loaded by tools/p4_ab.py, never by the library).  The product build
+# (`make`) runs without P4_DEV: a P4_* knob left in the environment then stops the build instead of silently linking a stamped or
+# ablated code object into libpfa_hip.so.
+DEV = os.environ.get("P4_DEV", "") == "1"
+if not DEV:
+    _stray = sorted(k for k in os.environ if k.startswith("P4_"))
+    if _stray:
+        sys.exit(f"gen_fa3_fwd_p4.py: {', '.join(_stray)} set without P4_DEV=1 -- the product code object takes no experiment knobs")
+
+
+def knob(name, default):
+    return os.environ.get(name, default) if DEV else default
+
 # ------------------------------------------------------------------------------------------------------------------------------
 # LDS map (bytes): K ring 2 x 16 KiB, V ring 2 x 16 KiB, Q landing zone 4 waves x 16 KiB, O staging 4 waves x 8 KiB = 160 KiB
 # per kernel (Gen.__init__): TILE = 64 keys x D x 2 B (16 KiB at D = 128, 8 KiB at D = 64); K ring at 0, V ring at 2 TILE, the waves'
@@ -93,12 +108,12 @@ def PDL(X, i):              # split P: the low halves (the VGPRs the 4-deep frag
     return 176 + (0 if X == 'A' else 16) + i
 
 
-PKADD = int(os.environ.get("P4_PKADD", "0"))        # EXPERIMENT, off: row sums as v_pk_add_f32 on register pairs (32 instead of 64 instructions a tile) ran 5-7 % SLOWER
-SEAM = int(os.environ.get("P4_SEAM", "1"))          # the item seam as one more FULL iteration (kernel(), body_seam): 0 = LAST body, epilogue, prologue one after the other
-ILV = int(os.environ.get("P4_ILV", "1"))            # the FULL body's softmax streams of strips A and B interleaved instruction by instruction
-WAITN = int(os.environ.get("P4_WAITN", "2"))        # LDS fragments waited for at a time (2: 8 s_waitcnt per phase; 4: 4)
-LEAN = int(os.environ.get("P4_LEAN", "1"))          # the tile loop's lean path (kernel()): 0 = every iteration carries the full bookkeeping
-RING = int(os.environ.get("P4_RING", "8"))          # K / V^T fragment rings: 4 (VGPRs) or 8 (the spare accumulator registers a[192:255])
+PKADD = int(knob("P4_PKADD", "0"))        # EXPERIMENT, off: row sums as v_pk_add_f32 on register pairs (32 instead of 64 instructions a tile) ran 5-7 % SLOWER
+SEAM = int(knob("P4_SEAM", "1"))          # the item seam as one more FULL iteration (kernel(), body_seam): 0 = LAST body, epilogue, prologue one after the other
+ILV = int(knob("P4_ILV", "1"))            # the FULL body's softmax streams of strips A and B interleaved instruction by instruction
+WAITN = int(knob("P4_WAITN", "2"))        # LDS fragments waited for at a time (2: 8 s_waitcnt per phase; 4: 4)
+LEAN = int(knob("P4_LEAN", "1"))          # the tile loop's lean path (kernel()): 0 = every iteration carries the full bookkeeping
+RING = int(knob("P4_RING", "8"))          # K / V^T fragment rings: 4 (VGPRs) or 8 (the spare accumulator registers a[192:255])
 KFR = lambda i: (192 + 4 * (i % 8)) if RING == 8 else (176 + 4 * (i % 4))
 VFR = lambda i: (224 + 4 * (i % 8)) if RING == 8 else (192 + 4 * (i % 4))
 KOFF = lambda ks: 208 + ks
@@ -127,11 +142,11 @@ V_T = [250, 251, 252, 253]
 V_TA = 254            # causal: r + 1 - 4h (element-mask threshold of the diagonal tile, see mask_diag)
 V_LANE = 255
 V_E = list(range(0, 16))   # prologue / epilogue / rescale scratch (v0 = workitem id at entry)
-STAMP = int(os.environ.get("P4_STAMP", "0"))      # 1: every phase; 2: one stamp per iteration only (buckets 0 / 1 stay empty); 3: kernel totals only (lean loop and pipelined seam stay on)
-ABL = os.environ.get("P4_ABL", "")                                         # timing-only ablations, see dma_plan
-DMA_PRICE = int(os.environ.get("P4_DMA_PRICE", "30"))                      # issue cycles budgeted for one LDS-DMA piece
-DMA_GAPS_V = [int(x) for x in os.environ.get("P4_DMA_GAPS_V", "1,5,9,13").split(",")]      # QK^T gaps that carry the V(j+1) pieces
-DMA_GAPS_K = [int(x) for x in os.environ.get("P4_DMA_GAPS_K", "17,21,25,27").split(",")]   # ... and the K(j+2) pieces
+STAMP = int(knob("P4_STAMP", "0"))      # 1: every phase; 2: one stamp per iteration only (buckets 0 / 1 stay empty); 3: kernel totals only (lean loop and pipelined seam stay on)
+ABL = knob("P4_ABL", "")                                         # timing-only ablations, see dma_plan
+DMA_PRICE = int(knob("P4_DMA_PRICE", "30"))                      # issue cycles budgeted for one LDS-DMA piece
+DMA_GAPS_V = [int(x) for x in knob("P4_DMA_GAPS_V", "1,5,9,13").split(",")]      # QK^T gaps that carry the V(j+1) pieces
+DMA_GAPS_K = [int(x) for x in knob("P4_DMA_GAPS_K", "17,21,25,27").split(",")]   # ... and the K(j+2) pieces
 NEG_BIG = "0xf149f2ca"     # -1e30f
 NEG_INF = "0xff800000"
 

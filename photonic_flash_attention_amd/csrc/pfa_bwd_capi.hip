@@ -29,7 +29,24 @@ int check_bwd(const pfa_fa3_bwd_args* a) {
                                a->v_stride_b, a->v_stride_h, a->v_stride_s};
         for (int64_t s : st4)
             if (s % 4) return PFA_ERR_STRIDE;
-        if (!al16(a->q) || !al16(a->k) || !al16(a->v)) return PFA_ERR_ALIGN;
+        // dout is read in 16-byte pieces like q / k / v (fa3_bwd_f32_kernel MODE 0); o and the gradients are 4-byte accesses
+        const int64_t do4[] = {a->do_stride_b, a->do_stride_h, a->do_stride_s};
+        for (int64_t s : do4)
+            if (s % 4) return PFA_ERR_STRIDE;
+        if (!al16(a->q) || !al16(a->k) || !al16(a->v) || !al16(a->dout)) return PFA_ERR_ALIGN;
+        const void* p4[] = {a->o, a->dq, a->dk, a->dv, a->lse};
+        for (const void* p : p4)
+            if (reinterpret_cast<uintptr_t>(p) & 3u) return PFA_ERR_ALIGN;
+        // row strides: non-negative, rows at least D apart, every tensor addressable with 32-bit element offsets inside one (b, h) slab
+        const int64_t rows[] = {a->q_stride_s, a->k_stride_s, a->v_stride_s, a->o_stride_s, a->do_stride_s, a->dq_stride_s, a->dk_stride_s,
+                                a->dv_stride_s};
+        for (int64_t s : rows)
+            if (s < a->D) return PFA_ERR_STRIDE;
+        const int64_t ext[] = {(int64_t)(a->Sq - 1) * a->q_stride_s, (int64_t)(a->Sk - 1) * a->k_stride_s, (int64_t)(a->Sk - 1) * a->v_stride_s,
+                               (int64_t)(a->Sq - 1) * a->o_stride_s, (int64_t)(a->Sq - 1) * a->do_stride_s, (int64_t)(a->Sq - 1) * a->dq_stride_s,
+                               (int64_t)(a->Sk - 1) * a->dk_stride_s, (int64_t)(a->Sk - 1) * a->dv_stride_s};
+        for (int64_t e : ext)
+            if ((e + a->D) * 4 > 0x7fffffffLL) return PFA_ERR_SHAPE;
         return PFA_OK;
     }
     if (a->drop_mask) return PFA_ERR_FLAGS;

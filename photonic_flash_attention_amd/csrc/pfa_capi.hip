@@ -1,6 +1,6 @@
 // pfa_capi.hip -- the C ABI of libpfa_hip.so (see include/pfa_hip.h for the contract and the
 // reference lines each entry point replaces).  Host side only validates, picks a kernel variant
-// and enqueues it; no allocation, no synchronisation, no global mutable state.
+// and enqueues it; no allocation, no synchronisation; the only process-wide state is pfa_p4.hip's per-device module handle.
 #include "pfa_hip.h"
 
 #include <hip/hip_runtime.h>
@@ -9,10 +9,6 @@
 #include <string.h>
 
 #include "fa3_fwd_kernel.h"
-#ifdef PFA_DEV_VARIANTS      // development build only (make DEV=1): schedule experiments and timing-only ablations, see pick()
-#include "fa3_fwd_pipe_kernel.h"
-#include "fa3_fwd_stagger_kernel.h"
-#endif
 #include "fa3_weights_kernel.h"
 #include "fa3_fwd_f32_kernel.h"
 #include "pfa_p4.h"
@@ -38,12 +34,7 @@ struct Variant {
 template <typename T, int D, bool C, bool S, bool K, int VAR, typename OT>
 Variant mk(const char* tn, const char* on) {
     Variant v;
-#ifdef PFA_DEV_VARIANTS
-    if constexpr (VAR & pfa::VAR_STAGGER) v.fn = (const void*)&pfa::fa3_fwd_stagger_kernel<T, D, C, S, K, VAR, OT>;
-    else if constexpr (VAR & pfa::VAR_PIPE) v.fn = (const void*)&pfa::fa3_fwd_pipe_kernel<T, D, C, S, K, VAR, OT>;
-    else
-#endif
-        v.fn = (const void*)&pfa::fa3_fwd_kernel<T, D, C, S, K, VAR, OT>;
+    v.fn = (const void*)&pfa::fa3_fwd_kernel<T, D, C, S, K, VAR, OT>;
     snprintf(v.name, sizeof(v.name), "fa3_fwd_%s_d%d_%s%s%s_%s_v%d", tn, D, C ? "causal" : "full", S ? "_splitp" : "",
              K ? "_kmask" : "", on, VAR);
     v.lds_bytes = ((VAR & pfa::VAR_STAGE2) ? 4 : 2) * 2 * pfa::BLOCK_N * D * 2;
@@ -76,14 +67,6 @@ Variant by_d(int D, bool causal, bool split, bool kmask, bool out32, const char*
     return D == 128 ? by_causal<T, 128>(causal, split, kmask, out32, tn) : by_causal<T, 64>(causal, split, kmask, out32, tn);
 }
 
-#ifdef PFA_DEV_VARIANTS
-// Experimental variants (A/B only): bf16, D=128, single-P, bf16 store; selected by flags bits 8..15.
-template <int VAR>
-Variant exp_variant(bool causal) {
-    return causal ? mk<__bf16, 128, true, false, false, VAR, __bf16>("bf16", "o16")
-                  : mk<__bf16, 128, false, false, false, VAR, __bf16>("bf16", "o16");
-}
-#endif
 
 // persistent 4 waves x 64 rows in assembly (gen_fa3_fwd_p4.py / pfa_p4.hip)
 Variant p4_variant(const pfa_fa3_args* a, bool causal) {
@@ -140,64 +123,7 @@ Variant pick(const pfa_fa3_args* a) {
         const bool take = a->D == 128 || var == 45 || units <= v.p4_grid;
         if (v.p4_grid > 0 && take) return v;   // (0: the code object did not load on this device -- fall through to the HIP kernels)
     }
-#ifdef PFA_DEV_VARIANTS
-    if (w4_ok && (var == 47 || var == 48 || var == 49)) {      // A/B: head-grouped block order 2 / 4 / off
-        Variant v = w4_variant(a, causal, out32);
-        v.xcd_group = var == 47 ? 2 : (var == 48 ? 4 : 0);
-        return v;
-    }
-#endif
     if (w4_ok && (var == 43 || ((var == 0 || var == 45) && avg_tiles >= 16))) return w4_variant(a, causal, out32);
-#ifdef PFA_DEV_VARIANTS
-    if (var != 0 && var != 44 && a->dtype_in == PFA_DTYPE_BF16 && a->D == 128 && !split && !kmask && !out32) {
-        switch (var) {
-            case 1: return exp_variant<pfa::VAR_SCHED | pfa::VAR_GLDS | pfa::VAR_BUFDMA>(causal);          // exact lazy rescale (no defer-max)
-            case 2: return exp_variant<pfa::VAR_DEFER_MAX>(causal);                                         // register staging, compiler-ordered QK
-            case 3: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_SCHED>(causal);                        // + pinned QK read/MFMA interleave
-            case 4: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_SCHED | pfa::VAR_GLDS>(causal);        // + LDS-DMA (global_load_lds)
-            case 5: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_LSUM>(causal);                           // row sums on the matrix pipe
-            case 6: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_STAGE2>(causal);                         // two tiles per barrier
-            case 7: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_SCHED | pfa::VAR_GLDS | pfa::VAR_NW4>(causal);   // 2 x 4-wave workgroups per CU
-            case 8: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_PIPE | pfa::VAR_SCHED>(causal);        // half-tile software pipeline
-            case 9: return exp_variant<pfa::VAR_DEFER_MAX | pfa::VAR_STAGGER>(causal);                      // staggered wave halves
-            case 16: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_STAMP>(causal);                         // diagnostic stamps
-            case 10: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_DMA4>(causal);                          // older wave half issues all DMA
-            case 11: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_STAGE2 | pfa::VAR_ALTPRIO>(causal);     // alternate priority, barrier per 2 tiles
-            case 12: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_STAGE2 | pfa::VAR_ALTPRIO | pfa::VAR_DMA4>(causal);
-            case 13: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_ALTPRIO>(causal);
-            case 18: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_RING3>(causal);
-            case 19: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_RING3 | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV>(causal);
-            case 28: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV | pfa::ABL_NO_DMA>(causal);
-            case 29: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV | pfa::ABL_NO_DMA | pfa::ABL_NO_BARRIER>(causal);
-            case 30: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV | pfa::ABL_NO_DMA | pfa::ABL_NO_BARRIER | pfa::ABL_NO_LDS>(causal);
-            case 33: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV | pfa::ABL_NO_DMA | pfa::ABL_NO_BARRIER | pfa::ABL_NO_MFMA>(causal);
-            case 34: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV | pfa::ABL_NO_DMA | pfa::ABL_NO_BARRIER | pfa::ABL_AGPR_ACC>(causal);
-            case 35: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_XCDG2>(causal);
-            case 36: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_XCDG4>(causal);
-            case 37: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV | pfa::ABL_NO_DMA | pfa::ABL_NO_BARRIER | pfa::ABL_AGPR_OPND>(causal);
-            case 38: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV | pfa::ABL_NO_DMA | pfa::ABL_NO_BARRIER | pfa::VAR_PF8 | pfa::VAR_SETPRIO>(causal);
-            case 39: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_PF8 | pfa::VAR_SETPRIO>(causal);
-            case 31: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_DMA>(causal);
-            case 32: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_DMA | pfa::ABL_NO_BARRIER>(causal);
-            case 40: return exp_variant<pfa::VAR_DEFAULT & ~pfa::VAR_DIET>(causal);                           // before the VALU diet (reference for A/B)
-            case 41: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_MFMA16>(causal);                          // timing only: 16x16x32 MFMAs
-            case 42: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV | pfa::ABL_NO_DMA | pfa::ABL_NO_BARRIER | pfa::ABL_MFMA16>(causal);   // var 29 with 16x16x32
-            case 46: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_NW4>(causal);                             // 2 x 4-wave workgroups per CU, current default otherwise
-            case 14: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_QKIL>(causal);
-            case 15: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_PF8>(causal);
-            case 17: return exp_variant<pfa::VAR_DEFAULT | pfa::VAR_QKIL | pfa::VAR_PF8>(causal);
-            case 26: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV | pfa::VAR_QKIL>(causal);
-            case 27: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV | pfa::VAR_PF8>(causal);
-            case 20: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX>(causal);
-            case 21: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_PV>(causal);
-            case 22: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_QK>(causal);
-            case 23: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_EXP>(causal);
-            case 24: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_PV>(causal);
-            case 25: return exp_variant<pfa::VAR_DEFAULT | pfa::ABL_NO_SOFTMAX | pfa::ABL_NO_QK>(causal);
-            default: break;
-        }
-    }
-#endif
     return a->dtype_in == PFA_DTYPE_BF16 ? by_d<__bf16>(a->D, causal, split, kmask, out32, "bf16")
                                          : by_d<_Float16>(a->D, causal, split, kmask, out32, "fp16");
 }
@@ -209,15 +135,13 @@ int check(const pfa_fa3_args* a) {
     if (!a) return PFA_ERR_NULL;
     if (a->size != sizeof(pfa_fa3_args)) return PFA_ERR_STRUCT_SIZE;
     if (a->flags & ~(PFA_FLAG_SPLIT_P | PFA_FLAG_NO_XCD_MAP | PFA_FLAG_VARIANT_MASK)) return PFA_ERR_FLAGS;
-#ifndef PFA_DEV_VARIANTS
-    {   // the production library knows three kernel selectors (43 / 44 / 45, see pick()); development variants need make DEV=1
+    {   // the library knows three kernel selectors (43 / 44 / 45, see pick())
         const unsigned var = (a->flags & PFA_FLAG_VARIANT_MASK) >> 8;
         if (var != 0 && var != 43 && var != 44 && var != 45) return PFA_ERR_FLAGS;
     }
-#endif
     if (!a->q || !a->k || !a->v || !a->o) return PFA_ERR_NULL;
     if (a->key_mask && a->mask) return PFA_ERR_FLAGS;
-    if (a->kv_group < 0 || a->reserved0 != 0 || a->reserved1 != 0 || (a->kv_group > 1 && a->H % a->kv_group != 0)) return PFA_ERR_SHAPE;
+    if (a->kv_group < 0 || a->reserve_cus < 0 || a->reserved1 != 0 || (a->kv_group > 1 && a->H % a->kv_group != 0)) return PFA_ERR_SHAPE;
     if (a->drop_mask && (a->dtype_in != PFA_DTYPE_FP32 || !(a->drop_scale >= 1.f) || !isfinite(a->drop_scale))) return PFA_ERR_FLAGS;
     if (a->B <= 0 || a->H <= 0 || a->Sq <= 0 || a->Sk <= 0) return PFA_ERR_SHAPE;
     if (a->D != 64 && a->D != 128) return PFA_ERR_HEAD_DIM;
@@ -234,6 +158,12 @@ int check(const pfa_fa3_args* a) {
         if (!(a->softmax_scale > 0.f) || !isfinite(a->softmax_scale)) return PFA_ERR_SHAPE;
         if ((int64_t)((a->Sq + 63) / 64) * a->B * a->H > 0x7fffffffLL) return PFA_ERR_SHAPE;
         if (a->lse && (reinterpret_cast<uintptr_t>(a->lse) & 3u)) return PFA_ERR_ALIGN;
+        const int64_t rows[] = {a->q_stride_s, a->k_stride_s, a->v_stride_s, a->o_stride_s};       // rows at least D apart, 32-bit slabs
+        for (int64_t s : rows)
+            if (s < a->D) return PFA_ERR_STRIDE;
+        if (((int64_t)(a->Sq - 1) * a->q_stride_s + a->D) * 4 > 0x7fffffffLL || ((int64_t)(a->Sk - 1) * a->k_stride_s + a->D) * 4 > 0x7fffffffLL ||
+            ((int64_t)(a->Sk - 1) * a->v_stride_s + a->D) * 4 > 0x7fffffffLL || ((int64_t)(a->Sq - 1) * a->o_stride_s + a->D) * 4 > 0x7fffffffLL)
+            return PFA_ERR_SHAPE;
         return PFA_OK;
     }
     if (!(a->softmax_scale > 0.f) || !isfinite(a->softmax_scale)) return PFA_ERR_SHAPE;
@@ -302,7 +232,17 @@ int pfa_device_supported(int device_id) {
         (void)hipGetLastError();
         return PFA_ERR_DEVICE;
     }
-    return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return 0;
+    int herr = 0;                   // load the assembly kernels' code object now: no later call (or graph capture) has to
+    if (pfa::p4_prepare(device_id, &herr) != PFA_OK) g_last_hip_error = herr;     // (the HIP kernels still serve the device)
+    return 1;
+}
+
+int pfa_fa3_prepare(int device_id) {
+    int herr = 0;
+    const int st = pfa::p4_prepare(device_id, &herr);
+    if (st != PFA_OK) g_last_hip_error = herr;
+    return st;
 }
 
 // Masks are condensed into one 64-bit word per mask row and 64-key tile before the forward (fa3_maskbits_kernel): geometry of

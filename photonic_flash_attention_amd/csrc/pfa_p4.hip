@@ -1,6 +1,7 @@
 // pfa_p4.hip -- host side of the persistent 4-wave forward (gen_fa3_fwd_p4.py): the kernel is gfx950 assembly assembled into a code
 // object of its own (build/fa3_fwd_p4.hsaco), embedded here byte for byte and loaded once per device with hipModuleLoadData.
-// The only process-wide state of the library: the per-device module handles, filled under a mutex and never changed afterwards.
+// The only process-wide state of the library: the per-device module handles, filled once under a mutex (pfa_fa3_prepare /
+// pfa_device_supported do it eagerly) and never changed afterwards.
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -60,30 +61,47 @@ struct DevMod {
     hipModule_t mod = nullptr;
     hipFunction_t fn[2][2][2][3][2] = {};  // [dtype][D: 128, 64][causal][plain, key mask, ragged][parity variant: fp32 store + split P]
     int n_cu = 0;
-    int state = 0;                   // 0 = not tried, 1 = ready, -1 = failed
+    int state = 0;                   // 0 = not loaded (yet), 1 = ready, -1 = permanently unavailable on this device
+    int last_err = 0;                // hipError_t of the last failed attempt
 };
 DevMod g_mod[MAX_DEV];
 std::mutex g_mu;
 
 uint32_t magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / d) + 1u; }   // n / d == mulhi(n, magic) while n * d < 2^32
 
-const DevMod* module_for(int dev) {
+// Load the code object on `dev` (once).  Permanent failures (the device is no gfx950 part, a kernel symbol is missing) latch
+// state = -1; transient ones (a failing HIP call, e.g. a first call issued under stream capture) leave state = 0 so that a later
+// call tries again; either way the hipError_t is kept for pfa_last_hip_error.  pfa_device_supported / pfa_fa3_prepare call this
+// eagerly, so that no launch, describe or graph capture ever loads a module.
+const DevMod* module_for(int dev, int* hip_err = nullptr) {
     if (dev < 0 || dev >= MAX_DEV) return nullptr;
-    std::lock_guard<std::mutex> lk(g_mu);
     DevMod& m = g_mod[dev];
+    if (__atomic_load_n(&m.state, __ATOMIC_ACQUIRE) == 1) return &m;          // the common case takes no lock
+    std::lock_guard<std::mutex> lk(g_mu);
     if (m.state == 0) {
-        m.state = -1;
+        auto fail = [&](hipError_t e, bool permanent) -> const DevMod* {
+            m.last_err = (int)e;
+            if (hip_err) *hip_err = (int)e;
+            (void)hipGetLastError();
+            if (permanent) m.state = -1;
+            return nullptr;
+        };
         int cur = -1;
-        if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        hipError_t e = hipGetDevice(&cur);
+        if (e != hipSuccess) return fail(e, false);
         struct Restore {       // the module belongs to the device that is current while it is loaded
             int cur, dev;
             Restore(int c, int d) : cur(c), dev(d) { if (c != d) (void)hipSetDevice(d); }
             ~Restore() { if (cur != dev) (void)hipSetDevice(cur); }
         } restore(cur, dev);
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        e = hipGetDeviceProperties(&prop, dev);
+        if (e != hipSuccess) return fail(e, false);
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return fail(hipErrorNoBinaryForGpu, true);
         m.n_cu = prop.multiProcessorCount;
-        if (hipModuleLoadData(&m.mod, pfa_p4_hsaco_begin) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        hipModule_t mod = nullptr;
+        e = hipModuleLoadData(&mod, pfa_p4_hsaco_begin);
+        if (e != hipSuccess) return fail(e, e == hipErrorNoBinaryForGpu || e == hipErrorInvalidImage || e == hipErrorSharedObjectInitFailed);
         static const char* dt[2] = {"bf16", "fp16"};
         static const char* cz[2] = {"full", "causal"};
         static const char* pv[2] = {"o16", "splitp_o32"};
@@ -94,13 +112,16 @@ const DevMod* module_for(int dev) {
                         for (int v = 0; v < 2; ++v) {
                             char name[64];
                             snprintf(name, sizeof(name), "fa3_fwd_p4_%s_d%d_%s%s_%s", dt[d], hd ? 64 : 128, cz[c], km == 1 ? "_km" : (km == 2 ? "_kl" : ""), pv[v]);
-                            if (hipModuleGetFunction(&m.fn[d][hd][c][km][v], m.mod, name) != hipSuccess) {
-                                (void)hipGetLastError();
-                                m.fn[d][hd][c][km][v] = nullptr;
-                                if (!km) return nullptr;          // (a diagnostic P4_STAMP build carries no key-mask kernels: those problems stay on the HIP kernels)
+                            e = hipModuleGetFunction(&m.fn[d][hd][c][km][v], mod, name);
+                            if (e != hipSuccess) {         // the production code object carries all 48 kernels: a missing one is a broken build
+                                (void)hipModuleUnload(mod);
+                                return fail(e, true);
                             }
                         }
-        m.state = 1;
+        m.mod = mod;
+        __atomic_store_n(&m.state, 1, __ATOMIC_RELEASE);
+    } else if (m.state < 0 && hip_err) {
+        *hip_err = m.last_err;
     }
     return m.state == 1 ? &m : nullptr;
 }
@@ -146,17 +167,26 @@ bool p4_eligible(const pfa_fa3_args* a) {
     return true;
 }
 
+// Grid of the persistent kernel: one workgroup per CU, minus the CUs the caller wants left to another kernel (pfa_fa3_args.reserve_cus:
+// a collective running beside the attention needs CUs of its own, the persistent workgroups never yield theirs), a multiple of 8 when
+// the heads map onto the XCDs.
+static int grid_for(const DevMod* m, const pfa_fa3_args* a) {
+    int n = m->n_cu - (a->reserve_cus > 0 ? a->reserve_cus : 0);
+    if (n < 8) n = 8;
+    const int BH = a->B * a->H;
+    return BH % 8 == 0 ? (n / 8) * 8 : n;
+}
+
+int p4_prepare(int device_id, int* hip_err) { return module_for(device_id, hip_err) ? PFA_OK : PFA_ERR_DEVICE; }
+
 int p4_workgroups(const pfa_fa3_args* a) {
     const DevMod* m = module_for(a->device_id);
-    if (!m) return 0;
-    if (!m->fn[a->dtype_in == PFA_DTYPE_BF16 ? 0 : 1][a->D == 64 ? 1 : 0][a->causal ? 1 : 0][p4_flavour(a)][a->dtype_out == PFA_DTYPE_FP32 ? 1 : 0]) return 0;
-    const int BH = a->B * a->H;
-    return BH % 8 == 0 ? (m->n_cu / 8) * 8 : m->n_cu;
+    return m ? grid_for(m, a) : 0;
 }
 
 // Enqueue.  Returns PFA_OK, or PFA_ERR_LAUNCH / PFA_ERR_DEVICE (hip error in *hip_err).
 int p4_launch(const pfa_fa3_args* a, void* stream, int* hip_err) {
-    const DevMod* m = module_for(a->device_id);
+    const DevMod* m = module_for(a->device_id, hip_err);
     if (!m) return PFA_ERR_DEVICE;
     P4Params p;
     memset(&p, 0, sizeof(p));
@@ -176,7 +206,7 @@ int p4_launch(const pfa_fa3_args* a, void* stream, int* hip_err) {
     p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
     p.thr = 8.0f / p.scale_log2;
     const int BH = a->B * a->H;
-    const int grid = p4_workgroups(a);
+    const int grid = grid_for(m, a);
     p.xcd_mode = BH % 8 == 0 ? 1u : 0u;
     p.hx = p.xcd_mode ? (uint32_t)(BH / 8) : (uint32_t)BH;
     p.SL = p.xcd_mode ? (uint32_t)(grid / 8) : (uint32_t)grid;

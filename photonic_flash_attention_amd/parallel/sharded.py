@@ -126,6 +126,8 @@ def sharded_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, caus
         m = kw["mask"]
         if m.dim() == 2 and plan[0] == "batch" and m.shape[0] == B:          # [B,Sk]
             m = m[rank * n:(rank + 1) * n]
+        elif m.dim() == 3 and plan[0] == "batch" and m.shape[0] == B and B > 1:    # [B,Sq|1,Sk]
+            m = m[rank * n:(rank + 1) * n]
         elif m.dim() == 4:
             if plan[0] == "batch" and m.shape[0] == B and B > 1:
                 m = m[rank * n:(rank + 1) * n]
