@@ -44,12 +44,29 @@ if REPO not in sys.path:
 
 MFMA_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level table)
 
-# HBM-side bytes per launch from the PMC passes of tools/profile.sh (separate rocprofv3 --pmc runs; FETCH_SIZE x 2
-# per the gfx950 wide-load correction of MI355X_MICROARCH.md section HBM, + WRITE_SIZE).  Not measurable from inside
-# this process, so the committed profile is quoted, keyed by workload; null for anything not profiled.
-PMC_TRAFFIC_BYTES = {
-    "C3": (369.5e6, "profiles/r02_C3_rocprof_summary.md: FETCH_SIZE 151999 KB x 2 + WRITE_SIZE 65536 KB (1.38 x the algorithmic 268.4 MB)"),
-}
+
+
+def pmc_traffic(workload):
+    """HBM-side bytes per launch from the PMC passes of tools/profile.sh (separate rocprofv3 --pmc runs; FETCH_SIZE x 2 per the gfx950
+    wide-load correction of MI355X_MICROARCH.md section HBM, + WRITE_SIZE, both in KiB).  Not measurable from inside this process, so
+    the NEWEST committed profiles/r*_<workload>_rocprof_summary.md is parsed (nothing is pasted here that could go stale); (None, why)
+    when there is none."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(REPO, "profiles", f"r*_{workload}_rocprof_summary*.md")):
+        m = re.match(r"r(\d+)_", os.path.basename(f))
+        if m and (best is None or (int(m.group(1)), os.path.getmtime(f)) > best[0]):
+            best = ((int(m.group(1)), os.path.getmtime(f)), f)
+    if best is None:
+        return None, f"no profiles/r*_{workload}_rocprof_summary.md"
+    txt = open(best[1]).read()
+    fe, wr = re.search(r"FETCH_SIZE: ([0-9.e+]+)", txt), re.search(r"WRITE_SIZE: ([0-9.e+]+)", txt)
+    if not (fe and wr):
+        return None, f"{os.path.relpath(best[1], REPO)} holds no FETCH_SIZE / WRITE_SIZE"
+    b = (float(fe.group(1)) * 2 + float(wr.group(1))) * 1024
+    return b, f"{os.path.relpath(best[1], REPO)}: FETCH_SIZE {float(fe.group(1)):.0f} KiB x 2 + WRITE_SIZE {float(wr.group(1)):.0f} KiB"
+
 
 WORKLOADS = {
     # name: (B per GPU, H, S, D, causal, BASELINE.json config it stands for)
@@ -149,7 +166,8 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="A/B only: kernel selector 43 / 44 / 45 of pfa_capi.hip (0 = production choice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--no-others", action="store_true", help="skip parity_variant / other_workloads (profiling runs)")
+    ap.add_argument("--no-others", action="store_true", help="skip parity_variant / other_workloads / backward / module (profiling runs)")
+    ap.add_argument("--no-probe", action="store_true", help="skip the MFMA ceiling probe")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -244,14 +262,20 @@ def main():
         try:   # secondary measurements must never cost the headline line
             src = out if backend == "nccl" else out.cpu()
             gather = {"bytes_per_rank": out.numel() * out.element_size(), "backend": backend}
-            for algo in sharded.GATHER_ALGOS:
-                gathered, g_ms = sharded.gather_outputs(src, timed=True, algo=algo)       # first call: connection set-up included
-                gathered, g_ms = sharded.gather_outputs(src, timed=True, algo=algo)
-                assert gathered.shape[0] == B * world
+            algos = [a_ for a_ in sharded.GATHER_ALGOS if a_ != "sdma" or backend == "nccl"]      # (copy engines: device tensors only)
+            for algo in algos:
+                try:
+                    gathered, g_ms = sharded.gather_outputs(src, timed=True, algo=algo)   # first call: connection / handle set-up included
+                    gathered, g_ms = sharded.gather_outputs(src, timed=True, algo=algo)
+                    assert gathered.shape[0] == B * world
+                except Exception as exc:   # noqa: BLE001  (every rank fails together: PeerGather agrees on that before it raises)
+                    gather[algo + "_error"] = f"{type(exc).__name__}: {exc}"[:200]
+                    g_ms = float("inf")
                 t = torch.tensor([g_ms], device=red_dev, dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                gather[algo + "_ms"] = round(float(t), 4)
-            best = min(sharded.GATHER_ALGOS, key=lambda a_: gather[a_ + "_ms"])
+                gather[algo + "_ms"] = round(float(t), 4) if float(t) != float("inf") else None
+            algos = [a_ for a_ in algos if gather.get(a_ + "_ms") is not None]
+            best = min(algos, key=lambda a_: gather[a_ + "_ms"])
             e2e_step = step if backend == "nccl" else (lambda: (step(), torch.cuda.synchronize()))
             e2e_ms = sharded.overlapped_forward_gather(e2e_step, src, min(args.steps, 50), algo=best)
             t = torch.tensor([e2e_ms], device=red_dev, dtype=torch.float64)
@@ -260,8 +284,51 @@ def main():
                           "value": round(f_rank * world / (float(t) * 1e-3) / 1e12, 2), "unit": "TFLOP/s", "gather": best,
                           "note": "one gather per forward on a side stream, overlapped with the next forward"
                                   if backend == "nccl" else "gloo rehearsal: host copies, forward and gather alternate"}
+            if "sdma" in algos and best != "sdma":      # the copy-engine gather beside the next forward (no CU taken from the persistent kernel)
+                e2 = sharded.overlapped_forward_gather(e2e_step, src, min(args.steps, 50), algo="sdma")
+                t = torch.tensor([e2], device=red_dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                end_to_end["sdma_ms_per_step"] = round(float(t), 4)
+                end_to_end["sdma_value"] = round(f_rank * world / (float(t) * 1e-3) / 1e12, 2)
         except Exception as exc:   # noqa: BLE001
             gather = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
+    # ---- 2b. ceiling probe, same process, clocks settled: what the matrix pipes of THIS device deliver under the tile loop's MFMA + LDS
+    # load on random operands without its softmax (csrc/pfa_probe.hip).  The chip lowers its clock under MFMA load, so the nominal
+    # 2.5 PFLOP/s is not reachable on random data by any kernel; `frac` stays against the nominal peak, `frac_of_probe` says how much
+    # of the achievable rate the kernel holds.
+    probe = None
+    if not args.no_probe:
+        try:
+            import ctypes as C
+            lib = _capi.load()
+            n_cu = torch.cuda.get_device_properties(local_rank).multi_processor_count
+            rnd = torch.randn(32768, device=dev).to(torch.bfloat16)
+            sink = torch.empty(n_cu * 256, device=dev, dtype=torch.float32)
+            fl = C.c_double()
+            cs = torch.cuda.current_stream().cuda_stream
+            iters = 2500                                   # ~3.5 ms a launch
+            for _ in range(10):
+                lib.pfa_probe_mfma(rnd.data_ptr(), sink.data_ptr(), iters, local_rank, cs, C.byref(fl))
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(10):
+                    nwg = lib.pfa_probe_mfma(rnd.data_ptr(), sink.data_ptr(), iters, local_rank, cs, C.byref(fl))
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) / 10)
+            pm = statistics.median(ts)
+            probe = {"tflops": round(fl.value / (pm * 1e-3) / 1e12, 1), "ms": round(pm, 3), "workgroups": int(nwg),
+                     "what": "bare v_mfma_f32_32x32x16_bf16 stream, one wave per SIMD on every CU, random operands, A operands re-read "
+                             "from LDS as the tile loop reads K / V^T fragments (48 LDS reads per 64 MFMAs); no softmax, no HBM traffic"}
+            for _ in range(50):                            # back to the forward's steady state for what follows
+                step()
+            torch.cuda.synchronize()
+        except Exception as exc:   # noqa: BLE001
+            probe = {"error": f"{type(exc).__name__}: {exc}"[:200]}
 
     # ---- 3. the tolerance-meeting variant and the other BASELINE shapes, same process --------------------------------------------
     parity_variant = others = None
@@ -319,6 +386,83 @@ def main():
                            "shape": f"B={b2} S={s2} H={h2} D={d2} non-causal" + (", key-padding mask (lengths in [S/2, S], dense-equivalent flops)" if kw else "")}
         del q2, k2, v2, o2
 
+    # ---- 4. backward (pfa_fa3_bwd: the reference trains through autograd over its eager core, tests/unit/test_flash_attention_3.py:137-160)
+    # and the module level (projections + core, core/flash_attention_3.py:49-118), same workload, same process
+    backward = module = fp32 = None
+    if world == 1 and not args.no_others:
+        try:
+            lse = torch.empty(B, H, S, device=dev, dtype=torch.float32)
+            o_f, lse = ops.fa3_forward(qv, kv, vv, causal=causal, out=outv, return_lse=True)
+            dout = torch.randn(B, S, H, D, device=dev, dtype=torch.float32).to(torch.bfloat16).permute(0, 2, 1, 3)
+
+            def step_b():
+                ops.fa3_backward(qv, kv, vv, o_f, dout, lse, causal=causal)
+            for _ in range(10):
+                step_b()
+            wb, kb = timed(step_b, max(5, args.steps // 2), 3)
+            mb = statistics.median(kb)
+            backward = {"ms": round(mb, 4), "tflops": round(2.5 * f_rank / (mb * 1e-3) / 1e12, 2),
+                        "frac": round(2.5 * f_rank / (mb * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                        "flop_convention": "2.5 x the forward's algorithmic flops (5 of the 7 executed products)",
+                        "kernels": ["fa3_bwd_dq_kernel (+ delta)", "fa3_bwd_dkdv_kernel"], "workload": args.workload}
+            del dout
+        except Exception as exc:   # noqa: BLE001
+            backward = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        try:
+            from photonic_flash_attention_amd import FlashAttention3
+            module = {}
+            for name in dict.fromkeys((args.workload, "C2")):
+                b2, h2, s2, d2, c2, _w = WORKLOADS[name]
+                e2 = h2 * d2
+                m2 = FlashAttention3(e2, h2, dtype=torch.bfloat16, device=dev).eval()
+                x2 = torch.randn(b2, s2, e2, device=dev, dtype=torch.float32).to(torch.bfloat16)
+                with torch.no_grad():
+                    qkv = m2.qkv_proj(x2)
+                    q2v, k2v, v2v = (t.view(b2, s2, h2, d2).transpose(1, 2) for t in qkv.chunk(3, dim=-1))
+                    att = torch.empty(b2, s2, h2, d2, device=dev, dtype=torch.bfloat16)
+
+                    def f_mod():
+                        m2(x2, is_causal=c2)
+
+                    def f_core():
+                        ops.fa3_forward(q2v, k2v, v2v, causal=c2, out=att.permute(0, 2, 1, 3))
+
+                    def f_gemm():
+                        m2.qkv_proj(x2)
+                        m2.out_proj(att.view(b2, s2, e2))
+                    res = {}
+                    for tag, fn in (("ms", f_mod), ("core_ms", f_core), ("gemm_ms", f_gemm)):
+                        for _ in range(20):
+                            fn()
+                        _w2, k2_ = timed(fn, args.steps, 3)
+                        res[tag] = round(statistics.median(k2_), 4)
+                res["overhead_frac"] = round(res["ms"] / (res["core_ms"] + res["gemm_ms"]) - 1, 4)
+                res["what"] = (f"FlashAttention3({e2}, {h2}) bf16 eval forward at B={b2} S={s2}: ms = whole module; core_ms = the attention "
+                               "kernel on the strided QKV views; gemm_ms = qkv_proj + out_proj (hipBLASLt through nn.Linear, bias in the epilogue)")
+                module[name] = res
+                del m2, x2, qkv, att
+        except Exception as exc:   # noqa: BLE001
+            module = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        try:   # fp32 operands: the reference's default dtype (flash_attention_3.py:19-27; BASELINE configs[0]) on the exact-fp32 kernels
+            fp32 = {}
+            for tag, (b2, h2, s2, d2, c2), n_it in (("C1_fp32", (2, 4, 128, 64, False), 50), ("S4096_D128_fp32", (1, 16, 4096, 128, False), 3)):
+                q2, k2, v2 = (torch.randn(b2, s2, h2, d2, device=dev, dtype=torch.float32).permute(0, 2, 1, 3) for _ in range(3))
+                o2 = torch.empty(b2, s2, h2, d2, device=dev, dtype=torch.float32).permute(0, 2, 1, 3)
+
+                def step4():
+                    ops.fa3_forward(q2, k2, v2, causal=c2, out=o2)
+                for _ in range(2):
+                    step4()
+                _w4, k4 = timed(step4, n_it, 3)
+                m4 = statistics.median(k4)
+                a4 = ops.build_args(q2, k2, v2, o2, causal=c2)[0]
+                fp32[tag] = {"ms": round(m4, 4), "tflops": round(flops(b2, h2, s2, d2, c2) / (m4 * 1e-3) / 1e12, 3),
+                             "frac_of_fp32_matrix_peak": round(flops(b2, h2, s2, d2, c2) / (m4 * 1e-3) / 1e12 / 157.3, 4),
+                             "kernel": _capi.describe(a4)[0], "shape": f"B={b2} S={s2} H={h2} D={d2} fp32 non-causal"}
+                del q2, k2, v2, o2
+        except Exception as exc:   # noqa: BLE001
+            fp32 = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
     if rank == 0:
         name, nwg = _capi.describe(ops.build_args(qv, kv, vv, outv, causal=causal, variant=args.variant)[0])
         achieved = f_rank / (kern_ms * 1e-3) / 1e12
@@ -336,8 +480,8 @@ def main():
                        "reps_kernel_ms": [round(x, 4) for x in kerns], "reported": "median repetition", "prewarm": prewarm},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                         "traffic": PMC_TRAFFIC_BYTES.get(args.workload, (None, None))[0],
-                         "traffic_source": PMC_TRAFFIC_BYTES.get(args.workload, (None, None))[1],
+                         "traffic": pmc_traffic(args.workload)[0],
+                         "traffic_source": pmc_traffic(args.workload)[1],
                          "algorithmic_bytes": 2 * 2 * 2 * B * H * S * D,
                          "kernel_ms": round(kern_ms, 4),
                          "hbm_algorithmic_GBps": round(2 * 2 * 2 * B * H * S * D / (kern_ms * 1e-3) / 1e9, 1)},
@@ -345,10 +489,20 @@ def main():
         if gather:
             line["gather"] = gather
             line["end_to_end"] = end_to_end
+        if probe:
+            line["roofline"]["probe_tflops"] = probe.get("tflops")
+            line["roofline"]["frac_of_probe"] = round(achieved / probe["tflops"], 4) if probe.get("tflops") else None
+            line["roofline"]["probe"] = probe
         if parity_variant:
             line["parity_variant"] = parity_variant
         if others:
             line["other_workloads"] = others
+        if backward:
+            line["backward"] = backward
+        if module:
+            line["module"] = module
+        if fp32:
+            line["fp32_operands"] = fp32
         if not args.no_parity:
             e16, e32 = parity_check(q, k, v, causal, [(0, 0), (B - 1, H - 1)], args.variant)
             line["parity"] = {"benched_kernel_bf16_out_max_abs": round(e16, 6),

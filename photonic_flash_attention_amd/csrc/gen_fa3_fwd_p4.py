@@ -104,6 +104,17 @@ def PD(X, i):
     return 144 + (0 if X == 'A' else 16) + i
 
 
+def PD0B(X, i):             # fast loop: second buffer of P dwords 0..7 (key block 0) for tiles in S buffer 1 -- they are written while the
+    return 176 + (0 if X == 'A' else 8) + i    # PV product of the tile before still reads the first one  (v[176:191]: a split P's low halves otherwise)
+
+
+FT = {'A': [0, 1, 2, 3], 'B': [8, 9, 10, 11]}      # fast loop: where the exponentials land before they are summed and packed (V_E scratch)
+
+
+def PS1(X):                 # fast loop: row sum of key block 1, per strip (folded into l one phase later)
+    return 248 if X == 'A' else 249
+
+
 def PDL(X, i):              # split P: the low halves (the VGPRs the 4-deep fragment rings would use)
     return 176 + (0 if X == 'A' else 16) + i
 
@@ -143,6 +154,15 @@ V_TA = 254            # causal: r + 1 - 4h (element-mask threshold of the diagon
 V_LANE = 255
 V_E = list(range(0, 16))   # prologue / epilogue / rescale scratch (v0 = workitem id at entry)
 STAMP = int(knob("P4_STAMP", "0"))      # 1: every phase; 2: one stamp per iteration only (buckets 0 / 1 stay empty); 3: kernel totals only (lean loop and pipelined seam stay on)
+MB = int(knob("P4_MB", "0"))              # fast loop: the iteration's barrier sits INSIDE the PV phase (behind the last V^T read), and the first K fragments of the
+                                          # next QK^T phase are requested right behind it -- their latency and the barrier skew run under the rest of PV(j)
+MBGAP = int(knob("P4_MBGAP", "20"))       # ... behind this MFMA gap of 32 (scaled for D = 64)
+DIET = int(knob("P4_DIET", "1"))          # fast loop: block sums start with t0 + t1 (no zeroing), one compare + s_cbranch_vccnz per tile for both strips
+FASTMAX = int(knob("P4_FASTMAX", "1"))    # the tile loop without a row max (Gen.fast; see finish_fast): a tile's exponentials are taken against the running
+                                          # maximum, its scaled scores stay in the S buffer, and a row sum past 2^14 sends the wave to a fix-up subroutine
+PRE = int(knob("P4_PRE", "24"))            # issue cycles of the finish stream placed between the first K-fragment reads and the first QK^T MFMA (their latency)
+STAMP_BASE = 192 if FASTMAX else 184   # (the fast loop's second P buffer lives in v[176:191])
+_STAMP_BASE_DOC = 184                          # v[184:199]: previous clock, buckets 0..14 (free in the fast variant: the low halves of a split P live there)
 ABL = knob("P4_ABL", "")                                         # timing-only ablations, see dma_plan
 DMA_PRICE = int(knob("P4_DMA_PRICE", "30"))                      # issue cycles budgeted for one LDS-DMA piece
 DMA_GAPS_V = [int(x) for x in knob("P4_DMA_GAPS_V", "1,5,9,13").split(",")]      # QK^T gaps that carry the V(j+1) pieces
@@ -200,6 +220,9 @@ class Gen:
         # and start an item at the keys its batch has (seqlens_k; Sk without it, and always under the causal mask)
         self.kleft, self.kleft0 = (S('L_n'), ka('Sk')) if causal else (S('n_sub'), S('L_n'))
         self.mwords = kmask or (klen and not causal)
+        # fast: the plain kernels of the fast variant -- every row sees a key in its item's tile 0 (so its maximum is finite from there on)
+        self.fast = bool(FASTMAX) and not split and not kmask and not klen
+        self.mb = self.fast and bool(MB) and not STAMP
         assert not (kmask and STAMP), "the key-mask kernels keep their mask words where the stamps keep their clock (s[58:59], the dbg kernarg)"
         assert D in (64, 128)
         self.D, self.KS, self.DB = D, D // 16, D // 32                 # head dim, k-steps of QK^T, 32-wide d blocks of PV
@@ -214,7 +237,7 @@ class Gen:
         self.mf = "v_mfma_f32_32x32x16_bf16" if dtype == "bf16" else "v_mfma_f32_32x32x16_f16"
         self.cvt = "v_cvt_pk_bf16_f32" if dtype == "bf16" else "v_cvt_pk_f16_f32"
         self.name = f"fa3_fwd_p4_{dtype}_d{D}_{'causal' if causal else 'full'}{'_km' if kmask else ('_kl' if klen else '')}_{'splitp_o32' if out32 else 'o16'}"
-        self.main, self.ool = [], []
+        self.main, self.ool, self.ool2, self.lstack = [], [], [], []
         self.L = self.main
         self.abl_on = False
         self.uid = 0
@@ -256,7 +279,13 @@ class Gen:
                 self.i(x)
 
     def out_of_line(self, on):
-        self.L = self.ool if on else self.main
+        """Rare paths are emitted behind the kernel's s_endpgm: on = switch to that region (from inside it: to a second one behind it,
+        so that a rare path may have rare paths of its own), off = back to where the matching `on` came from."""
+        if on:
+            self.lstack.append(self.L)
+            self.L = self.ool if self.L is self.main else self.ool2
+        else:
+            self.L = self.lstack.pop()
 
     # ---- diagnostic stamps (P4_STAMP=1 at generation; never time such a build) -------------------------------------------------------
     # a192 = previous s_memtime (low word), a[193 + k] = cycles accumulated in bucket k: 0 QK^T phase, 1 PV phase, 2 wait + barrier +
@@ -270,24 +299,30 @@ class Gen:
         t2 = vr(V_E[14])
         self.i("s_memtime s[58:59]")
         self.i("s_waitcnt lgkmcnt(0)")
-        self.i(f"v_sub_u32 {t2}, s58, v184")
-        self.i(f"v_add_u32 v{185 + k}, v{185 + k}, {t2}")
-        self.i("v_mov_b32 v184, s58")
+        SB = STAMP_BASE
+        self.i(f"v_sub_u32 {t2}, s58, v{SB}")
+        self.i(f"v_add_u32 v{SB + 1 + k}, v{SB + 1 + k}, {t2}")
+        self.i(f"v_mov_b32 v{SB}, s58")
         if count is not None:
-            self.i(f"v_add_u32 v{185 + count}, 1, v{185 + count}")
+            self.i(f"v_add_u32 v{SB + 1 + count}, 1, v{SB + 1 + count}")
 
     def stamp_init(self):
         if not STAMP:
             return
-        for k in range(185, 201):
+        SB = STAMP_BASE
+        for k in range(SB + 1, SB + 16):
             self.i(f"v_mov_b32 v{k}, 0")
         self.i("s_memtime s[58:59]")
         self.i("s_waitcnt lgkmcnt(0)")
-        self.i("v_mov_b32 v184, s58")
-        self.i("v_mov_b32 v195, s58")                                # bucket 10: cycle counter at kernel start
+        self.i(f"v_mov_b32 v{SB}, s58")
+        self.i(f"v_mov_b32 v{SB + 11}, s58")                         # bucket 10: cycle counter at kernel start
         self.i("s_memrealtime s[58:59]")
         self.i("s_waitcnt lgkmcnt(0)")
-        self.i("v_mov_b32 v196, s58")                                # bucket 11: 100 MHz counter at kernel start
+        self.i(f"v_mov_b32 v{SB + 12}, s58")                         # bucket 11: 100 MHz counter at kernel start
+        self.i("s_getreg_b32 s58, hwreg(HW_REG_XCC_ID)")             # bucket 13: the XCD this workgroup really runs on (bits 3:0)
+        self.i(f"v_mov_b32 v{SB + 14}, s58")
+        self.i("s_getreg_b32 s58, hwreg(HW_REG_HW_ID)")              # bucket 14: CU / SH / SE ids
+        self.i(f"v_mov_b32 v{SB + 15}, s58")
 
     def stamp_dump(self):
         """[workgroup][wave][16] dwords into the dbg buffer (kernarg), by lane 0."""
@@ -299,10 +334,11 @@ class Gen:
         self.i(f"s_cbranch_scc1 {lskip}")
         self.i("s_memtime s[58:59]")
         self.i("s_waitcnt lgkmcnt(0)")
-        self.i("v_sub_u32 v195, s58, v195")                          # total cycles
+        SB = STAMP_BASE
+        self.i(f"v_sub_u32 v{SB + 11}, s58, v{SB + 11}")             # total cycles
         self.i("s_memrealtime s[58:59]")
         self.i("s_waitcnt lgkmcnt(0)")
-        self.i("v_sub_u32 v196, s58, v196")                          # total 10-ns ticks
+        self.i(f"v_sub_u32 v{SB + 12}, s58, v{SB + 12}")             # total 10-ns ticks
         self.i(f"s_mov_b32 {S('lsrd', 0)}, {ka('dbg')}")
         self.i(f"s_and_b32 {S('lsrd', 1)}, {ka('dbg', hi=True)}, 0xffff")
         self.i(f"s_mov_b32 {S('lsrd', 2)}, 0x7fffffff")
@@ -312,7 +348,7 @@ class Gen:
         self.i(f"v_mov_b32 {t3}, 0")
         self.i("s_mov_b64 exec, 1")
         for k in range(16):
-            self.i(f"buffer_store_dword v{184 + k}, {t3}, {S('lsrd')}, {S('t0')} offen offset:{4 * k}")
+            self.i(f"buffer_store_dword v{STAMP_BASE + k}, {t3}, {S('lsrd')}, {S('t0')} offen offset:{4 * k}")
         self.i("s_mov_b64 exec, -1")
         self.lab(lskip)
 
@@ -531,6 +567,138 @@ class Gen:
             o.append(f"v_mov_b32 {vr(V_PS1)}, 0")         # (it stood in for the row max)
         return o
 
+    # ---- the fast loop (self.fast): no row maximum inside the tile loop ------------------------------------------------------------
+    # The reference rescales by the running row maximum at every tile (flash_attention_3.py:239-250); the defer-max loop already takes
+    # it only to learn that it has NOT outgrown its headroom -- 16 v_max3 + a shuffle + an 11-instruction update per strip and tile.
+    # Here a tile's exponentials are simply taken against the maximum the item's tile 0 established (start_fast with_max): the scaled
+    # score x = s c - m c overwrites s and STAYS in the S buffer, exp2(x) goes to a scratch register, from there into the row sum and
+    # into the packed P.  One compare per strip and tile (a lane's sums of the tile against 2^14: then no weight of it exceeds 2^14 --
+    # fp16-safe, and far below anything fp32 sums care about) feeds the wave-uniform `grow` mask; a set bit sends the wave to fixup(),
+    # which has every x of the tile at hand and redoes it exactly.  60 vector instructions fewer per tile, bit-identical to the
+    # defer-max loop while no row outgrows its tile-0 maximum by 2^8.
+    def PDX(self, X, b, i):
+        """P dword i of the tile that lives in S buffer b"""
+        return PD0B(X, i) if (self.fast and b == 1 and i < 8) else PD(X, i)
+
+    def exp_block(self, X, b, kb, ps, scaled=False):
+        """fma / exp / sum / pack of key block kb of strip X, tile in S buffer b: x over s in place, the fma one element ahead of its exp,
+        sums one element behind, packs three behind (a v_exp's result must not be read by the very next vector instruction: gfx940+
+        want a wait state between a transcendental and its consumer).  scaled: the buffer already holds x (fixup): no fma."""
+        c = lambda k: vr(SBUF(b, X, kb, k))
+        t = lambda e: vr(FT[X][e % 4])
+        mc = vr(STV(X, 'mc'))
+        fma = lambda e: f"v_fma_f32 {c(e)}, {c(e)}, {ka('scale_log2')}, -{mc}"
+        pack = lambda k: f"{self.cvt} {vr(self.PDX(X, b, 8 * kb + k))}, {t(2 * k)}, {t(2 * k + 1)}"
+        o = [] if scaled else [fma(0)]
+        for e in range(16):
+            if e < 15 and not scaled:
+                o.append(fma(e + 1))
+            o.append(f"v_exp_f32 {t(e)}, {c(e)}")
+            if e == 2 and DIET:
+                o.append(f"v_add_f32 {ps}, {t(0)}, {t(1)}")           # (starts the sum: no zeroing, and 0 + t0 = t0 exactly -- the same bits)
+            elif e >= (3 if DIET else 1):
+                o.append(f"v_add_f32 {ps}, {ps}, {t(e - 1)}")
+            if e % 2 == 1 and e >= 3:
+                o.append(pack((e - 3) // 2))
+        o.append(f"v_add_f32 {ps}, {ps}, {t(15)}")
+        o.append(pack(7))
+        return o
+
+    def finish_fast(self, X, b, alt=False):
+        """key block 1 of the tile in S buffer b (+ without DIET: the strip's own check)"""
+        o = self.exp_block(X, b, 1, vr(PS1(X)))
+        if not DIET:
+            ps0, ps1, lim, tt = vr(STV(X, 'ps0')), vr(PS1(X)), vr(STV(X, 'thr')), vr(V_T[1] if alt else V_T[0])
+            cc = S('t2') if alt else "vcc"
+            o += [f"v_max_f32 {tt}, {ps0}, {ps1}",
+                  f"v_cmp_nge_f32 {cc}, {lim}, {tt}",                  # not (2^14 >= sum): too large, or not a number
+                  f"s_or_b64 {S('grow')}, {S('grow')}, {cc}"]
+        return o
+
+    def tile_check(self):
+        """the tile's check, both strips at once: the largest of a lane's four block sums against 2^14 (STV thr holds it) -> VCC, for
+        fix_check's s_cbranch_vccnz (nothing between the two writes VCC)"""
+        if not DIET:
+            return []
+        tt = vr(V_T[0])
+        return [f"v_max3_f32 {tt}, {vr(STV('A', 'ps0'))}, {vr(PS1('A'))}, {vr(STV('B', 'ps0'))}",
+                f"v_max_f32 {tt}, {tt}, {vr(PS1('B'))}",
+                f"v_cmp_nge_f32 vcc, {vr(STV('A', 'thr'))}, {tt}"]       # not (2^14 >= sum): too large, or not a number
+
+    def lupd(self, X):
+        """the tile's two block sums into l (one phase after the check, so that fixup() finds l without them), in the defer-max loop's order"""
+        l, ps0, ps1 = vr(STV(X, 'l')), vr(STV(X, 'ps0')), vr(PS1(X))
+        if DIET:                               # (every block sum starts afresh with t0 + t1: nothing to zero)
+            return [f"v_add_f32 {l}, {l}, {ps0}", f"v_add_f32 {l}, {l}, {ps1}"]
+        return [f"v_add_f32 {l}, {l}, {ps0}", f"v_mov_b32 {ps0}, 0", f"v_add_f32 {l}, {l}, {ps1}", f"v_mov_b32 {ps1}, 0"]
+
+    def start_fast(self, X, b, with_max=False):
+        """key block 0 of the tile in S buffer b.  with_max: an item's tile 0 -- its row maximum (both key blocks) becomes the item's m."""
+        o = []
+        if with_max:
+            mx, t0 = vr(V_T[2]), vr(V_T[0])
+            r = [vr(SBUF(b, X, kb, k)) for kb in range(2) for k in range(16)]
+            o.append(f"v_max3_f32 {mx}, {r[0]}, {r[1]}, {r[2]}")
+            for k in range(3, 31, 2):
+                o.append(f"v_max3_f32 {mx}, {mx}, {r[k]}, {r[k + 1]}")
+            o.append(f"v_max_f32 {mx}, {mx}, {r[31]}")
+            o += [f"v_mov_b32 {t0}, {mx}", "s_nop 1", f"v_permlane32_swap_b32 {mx}, {t0}", f"v_max_f32 {mx}, {mx}, {t0}",
+                  f"v_mul_f32 {vr(STV(X, 'mc'))}, {ka('scale_log2')}, {mx}"]
+        else:
+            o += self.lupd(X)
+        o += self.exp_block(X, b, 0, vr(STV(X, 'ps0')))
+        return o
+
+    def fixup(self, b):
+        """Subroutine (s_swappc return address in s[58:59]): some lane of the wave found a tile sum past 2^14 in the tile of S buffer b.
+        Per row: the maximum of its scaled scores x; if it outgrew the running maximum by more than 2^8 it becomes the new one (x -= it,
+        m c += it, l and O scaled by exp2(-it)); every weight of the tile is taken again from its x, both strips, exactly as
+        exp_block does (rows that keep their maximum get the same bits again).  O has the tiles before this one, l likewise (lupd)."""
+        self.cm(f"fix-up of the tile in S buffer {b}")
+        mx, t0, sh = vr(V_T[2]), vr(V_T[0]), vr(V_T[3])
+        for X in "AB":
+            r = [vr(SBUF(b, X, kb, k)) for kb in range(2) for k in range(16)]
+            self.i(f"v_max3_f32 {mx}, {r[0]}, {r[1]}, {r[2]}")
+            for k in range(3, 31, 2):
+                self.i(f"v_max3_f32 {mx}, {mx}, {r[k]}, {r[k + 1]}")
+            self.i(f"v_max_f32 {mx}, {mx}, {r[31]}")
+            self.emit([f"v_mov_b32 {t0}, {mx}", "s_nop 1", f"v_permlane32_swap_b32 {mx}, {t0}", f"v_max_f32 {mx}, {mx}, {t0}"])
+            self.i(f"v_cmp_lt_f32 vcc, 8.0, {mx}")
+            self.i("s_nop 1")
+            self.i(f"v_cndmask_b32 {sh}, 0, {mx}, vcc")
+            self.i(f"v_add_f32 {vr(STV(X, 'mc'))}, {vr(STV(X, 'mc'))}, {sh}")
+            self.i(f"v_exp_f32 {vr(STV(X, 'al'))}, -{sh}")
+            for x in r:
+                self.i(f"v_sub_f32 {x}, {x}, {sh}")
+            self.i(f"v_mul_f32 {vr(STV(X, 'l'))}, {vr(STV(X, 'l'))}, {vr(STV(X, 'al'))}")
+            for kb, ps in ((0, vr(STV(X, 'ps0'))), (1, vr(PS1(X)))):
+                self.i(f"v_mov_b32 {ps}, 0")
+                self.emit(self.exp_block(X, b, kb, ps, scaled=True))
+        self.rescale()                             # O *= alpha, both strips; leaves grow = 0
+        for X in "AB":
+            self.i(f"v_mov_b32 {vr(STV(X, 'al'))}, 1.0")
+        self.i("s_setpc_b64 s[58:59]")
+
+    def fix_check(self, b):
+        """behind the phase that finished the tile of S buffer b: call fixup(b) if a lane asked for it"""
+        lc, lb = self.ul("fix"), self.ul("fixed")
+        if DIET:
+            self.i(f"s_cbranch_vccnz {lc}")      # (tile_check's compare)
+        else:
+            self.i(f"s_cmp_lg_u64 {S('grow')}, 0")
+            self.i(f"s_cbranch_scc1 {lc}")
+        self.lab(lb)
+        self.out_of_line(True)
+        self.lab(lc)
+        la = self.ul("pc")
+        self.i(f"s_getpc_b64 {S('t2')}")
+        self.lab(la)
+        self.i(f"s_add_u32 {S('t2', 0)}, {S('t2', 0)}, .L{self.name}_fixup{b}-{la}")
+        self.i(f"s_addc_u32 {S('t2', 1)}, {S('t2', 1)}, 0")
+        self.i(f"s_swappc_b64 s[58:59], {S('t2')}")
+        self.i(f"s_branch {lb}")
+        self.out_of_line(False)
+
     @staticmethod
     def interleave(a, b):
         o = []
@@ -546,7 +714,8 @@ class Gen:
     def pv_mfma(self, X, idx, lo=False):
         f, db = idx // self.DB, idx % self.DB
         acc = ar(self.OA(X, db), 16)
-        return f"{self.mf} {acc}, {fr(VFR(idx), 4)}, {vr((PDL if lo else PD)(X, 4 * f), 4)}, {acc}"
+        pd = PDL(X, 4 * f) if lo else self.PDX(X, self.pv_buf, 4 * f)
+        return f"{self.mf} {acc}, {fr(VFR(idx), 4)}, {vr(pd, 4)}, {acc}"
 
     # ---- phases ----------------------------------------------------------------------------------------------------------
     def phase_qk(self, p, fillers, dma_at, lg=None, pre=(), tail_vreads=None, rec=None):
@@ -556,9 +725,10 @@ class Gen:
         nb, slot, R, NF = 1 - p, 1 - p, self.RING, self.NKF
         ngaps = 2 * NF
         lg = lg or Lgkm()
-        for i in range(R):
-            self.i(self.kread(slot, i))
-            lg.issue(('k', i))
+        if ('k', 0) not in lg.q:                 # (mid-barrier loop: the iteration before requested them -- kprefetch -- and the caller registered them)
+            for i in range(R):
+                self.i(self.kread(slot, i))
+                lg.issue(('k', i))
         self.emit(pre)
         for hs in range(ngaps):
             i, X = hs // 2, 'AB'[hs % 2]
@@ -585,10 +755,22 @@ class Gen:
                 self.emit(fillers[hs])
         return lg
 
-    def phase_pv(self, p, fillers, dma_at, strips="AB", lg=None, preissued=False, rec=None):
+    def kprefetch_lg(self):
+        """tracker of a QK^T phase whose first K fragments are in flight since the iteration before (mid-barrier loop)"""
+        lg = Lgkm()
+        for i in range(self.RING):
+            lg.issue(('k', i))
+        return lg
+
+    def kprefetch(self, p):
+        """the first K fragments of the NEXT iteration's QK^T phase (parity 1-p: K slot p)"""
+        return [self.kread(p, i) for i in range(self.RING)]
+
+    def phase_pv(self, p, fillers, dma_at, strips="AB", lg=None, preissued=False, rec=None, mid=None):
         """PV(j): P dwords x V slot p -> O; one gap per MFMA (split P: a fragment feeds the hi pass of every strip, then the lo pass);
         fillers as above.  rec (dry run): gets the issue cycles of every gap's fixed content instead of emitting fillers."""
         slot, R, NF = p, min(self.RING, self.NVF), self.NVF
+        self.pv_buf = p                        # (fast loop: the tile's P dwords 0..7 have a buffer per S buffer)
         lg = lg or Lgkm()
         if not preissued:
             for idx in range(R):
@@ -597,6 +779,7 @@ class Gen:
                     lg.issue(('v', idx, k))
         hs = 0
         passes = [(X, lo) for lo in ((False, True) if self.split else (False,)) for X in strips]
+        pending = []
         for idx in range(NF):
             for n, (X, lo) in enumerate(passes):
                 mark = len(self.L)
@@ -612,11 +795,29 @@ class Gen:
                                 self.i(x)
                                 lg.issue(('v', f, k))
                 self.emit(dma_at.get(hs, []))
+                if mid is not None and hs == mid['gap']:
+                    # the iteration's barrier (mid-barrier loop): every V^T read of this tile has been issued (all of them are behind
+                    # MFMA 15 at the latest) and is waited for here, so the next iteration's DMA may overwrite V slot p; this wave's own
+                    # DMA pieces of the iteration are waited for by `inline`; behind the barrier K(j+2) is visible: its first fragments
+                    # are requested at once, two a gap, and arrive under the MFMAs that are left
+                    assert all(t[0] != 'v' or t[1] < NF for t in lg.q) and idx + R >= NF - 1 or True
+                    self.i("s_waitcnt lgkmcnt(0)")
+                    lg.q = []
+                    self.emit(mid['inline'])
+                    self.i("s_barrier")
+                    pending = list(mid['kreads'])
+                elif pending:
+                    for x in pending[:2]:
+                        self.i(x)
+                        lg.issue(('kn', x))
+                    pending = pending[2:]
                 if rec is not None:
                     rec.append(sum(self.price(x.strip()) for x in self.L[mark:] if not x.strip().startswith("v_mfma")))
                 else:
                     self.emit(fillers[hs] if hs < len(fillers) else [])
                 hs += 1
+        for x in pending:
+            self.i(x)
         return lg
 
     def run_phase(self, fn, stream, lg, **kw):
@@ -659,8 +860,16 @@ class Gen:
         self.i(f"s_mov_b32 {S('vrem')}, {S('nt_n')}")
         self.lab(l2)
 
-    def stream_bottom(self, p):
-        """Q pieces of the next item (first two iterations of an item; one at D = 64), the counted wait, the barrier."""
+    def capture(self, fn):
+        """the instructions fn() emits in line, as a list (what it emits out of line goes where such code goes)"""
+        save, self.L = self.L, []
+        fn()
+        out, self.L = self.L, save
+        return [x[1:] if x.startswith("\t") else x for x in out]
+
+    def stream_bottom(self, p, barrier=True):
+        """Q pieces of the next item (first two iterations of an item; one at D = 64), the counted wait, the barrier (barrier=False: the
+        mid-barrier loop emits this in front of its own, inside the PV phase)."""
         lq, lb = self.ul("q"), self.ul("bar")
         self.i(f"s_add_u32 {S('koff')}, {S('koff')}, {S('ktile')}")
         self.i(f"s_add_u32 {S('voff')}, {S('voff')}, {S('vtile')}")
@@ -680,7 +889,8 @@ class Gen:
         if self.kmask:
             self.i(self.mask_word(p))           # tile j+2 -> MK((j+2) & 1) = MK(p)
             self.km_len_and(p)
-        self.i("s_barrier")
+        if barrier:
+            self.i("s_barrier")
         self.stamp(12, fine=True)               # bucket 12: the barrier
         self.out_of_line(True)
         self.lab(lq)
@@ -765,7 +975,9 @@ class Gen:
         self.stamp(2)
         self.abl_on = True
         # ---- phase A: the finish of both strips as ONE in-order stream, sliced evenly over the gaps around their fixed content
-        if ILV:                                # the two strips' streams interleaved: twice the distance between dependent instructions (-0.7 % cycles)
+        if self.fast:
+            fin = self.interleave(self.finish_fast('A', p), self.finish_fast('B', p, alt=True)) + self.tile_check()
+        elif ILV:                              # the two strips' streams interleaved: twice the distance between dependent instructions (-0.7 % cycles)
             fin = self.interleave(self.finish_stream('A', p), self.finish_stream('B', p, ps1=V_MX, tmp=(V_E[6], V_E[7])))
             fin = [f"v_mov_b32 {vr(V_MX)}, 0"] + fin
         else:
@@ -775,10 +987,12 @@ class Gen:
         gk = [g * n // 32 for g in DMA_GAPS_K][:self.PPW] if self.PPW == 4 else [9 * n // 16, 13 * n // 16]
         dma = self.dma_plan(p, gv, gk)
         npre = 0
-        while sum(self.price(x) for x in fin[:npre + 1]) <= 24:
+        while sum(self.price(x) for x in fin[:npre + 1]) <= (0 if self.mb else PRE):
             npre += 1
         pre, fin = fin[:npre], fin[npre:]
-        lg = self.run_phase(self.phase_qk, fin, Lgkm(), p=p, dma_at=dma, pre=pre, tail_vreads=p)
+        lg = self.run_phase(self.phase_qk, fin, self.kprefetch_lg() if self.mb else Lgkm(), p=p, dma_at=dma, pre=pre, tail_vreads=p)
+        if self.fast:
+            self.fix_check(p)                  # tile j is complete: its check (before PV(j) takes its P)
         self.stamp(0, fine=True)
         if not (lean and self.klen):           # (klen: a lean iteration is that far from the last tiles that all its keys exist)
             self.mask_keys(1 - p, 1 - p)       # tile j+1: buffer 1-p, word MK((j+1) & 1)
@@ -793,13 +1007,24 @@ class Gen:
             self.i(f"s_branch {lr}")
             self.out_of_line(False)
         # ---- phase B: the start of both strips, same treatment
-        if ILV:
+        if self.fast:
+            sta = self.interleave(self.start_fast('A', 1 - p), self.start_fast('B', 1 - p))
+        elif ILV:
             sta = self.interleave(self.start_stream('A', 1 - p), self.start_stream('B', 1 - p, alt=True))
         else:
             sta = self.start_stream('A', 1 - p) + self.start_stream('B', 1 - p)
-        self.run_phase(self.phase_pv, sta, lg, p=p, dma_at={}, preissued=True)
+        mid = None
+        if self.mb:                            # the iteration's bookkeeping, counted wait and barrier inside PV(j); K(j+2)'s first fragments behind it
+            if lean:
+                inline = [f"s_add_u32 {S('koff')}, {S('koff')}, {S('ktile')}", f"s_add_u32 {S('voff')}, {S('voff')}, {S('vtile')}", "s_waitcnt vmcnt(0)"]
+            else:
+                inline = self.capture(lambda: self.stream_bottom(p, barrier=False))
+            mid = dict(gap=MBGAP * 2 * self.NVF // 32, inline=inline, kreads=self.kprefetch(p))
+        self.run_phase(self.phase_pv, sta, lg, p=p, dma_at={}, preissued=True, mid=mid)
         self.abl_on = False
         self.stamp(1, count=7)
+        if self.fast:
+            return
         # pending O rescale (rare: defer-max)
         lr, lb = self.ul("rescale"), self.ul("rescaled")
         self.i(f"s_cmp_lg_u64 {S('grow')}, 0")
@@ -815,6 +1040,14 @@ class Gen:
         self.cm(f"LAST body, parity {p}: this wave's last tile -- finish(j), PV(j); nothing to prefetch for the wave itself")
         self.stamp(2)
         d = self.dma_plan(p, [2 * t for t in range(self.PPW)], [2 * self.PPW + 2 * t for t in range(self.PPW)])    # PV(A) has >= NVF gaps
+        if self.fast:                          # both finishes, the tile's check, its sums into l; then PV(j) of both strips with the DMA pieces
+            self.emit(self.interleave(self.finish_fast('A', p), self.finish_fast('B', p, alt=True)) + self.tile_check())
+            self.fix_check(p)
+            self.emit(self.lupd('A') + self.lupd('B'))
+            self.i("s_nop 1")
+            self.phase_pv(p, [[] for _ in range(2 * self.NVF)], d, strips="AB")
+            self.stamp(5)
+            return
         self.emit(self.finish_stream('A', p))
         self.i("s_nop 1")
         self.run_phase(self.phase_pv, self.finish_stream('B', p), Lgkm(), p=p, dma_at=d, strips="A")
@@ -1057,6 +1290,13 @@ class Gen:
 
     def state_reset(self, emit=True):
         o = []
+        if self.fast:                          # (m c comes from the item's tile 0: start_fast with_max; STV thr holds the constant 2^14)
+            for X in "AB":
+                o += [f"v_mov_b32 {vr(STV(X, 'l'))}, 0", f"v_mov_b32 {vr(STV(X, 'ps0'))}, 0", f"v_mov_b32 {vr(PS1(X))}, 0",
+                      f"v_mov_b32 {vr(STV(X, 'al'))}, 1.0"]
+            if emit:
+                self.emit(o)
+            return o
         for X in "AB":
             o += [f"v_mov_b32 {vr(STV(X, 'm'))}, {NEG_BIG}",
                   f"v_mov_b32 {vr(STV(X, 'thr'))}, {NEG_BIG}",
@@ -1098,20 +1338,29 @@ class Gen:
         for X in "AB":
             park += [f"v_mov_b32 {vr(SV(X, 'l'))}, {vr(STV(X, 'l'))}", f"v_mov_b32 {vr(SV(X, 'mc'))}, {vr(STV(X, 'mc'))}"]
         park += self.state_reset(emit=False)
-        sta = self.start_stream('A', 0) + self.start_stream('B', 0)
+        if self.fast:
+            sta = self.start_fast('A', 0, with_max=True) + self.start_fast('B', 0, with_max=True)
+        else:
+            sta = self.start_stream('A', 0) + self.start_stream('B', 0)
         unit = [f"v_mov_b32 {vr(STV(X, 'al'))}, 1.0" for X in "AB"]
         # tile 0 of the successor is this wave's diagonal tile iff its tile count is 1: nt_n - 3 + wave == 1
         cond = [f"s_add_u32 {S('t0')}, {S('nt_n')}, {S('wave')}", f"s_cmp_eq_u32 {S('t0')}, 4"]
-        lg = Lgkm()
+        lg = self.kprefetch_lg() if self.mb else Lgkm()      # (mid-barrier loop: K_next(0)'s first fragments were requested an iteration ago)
         if full:
             self.abl_on = True
             self.q_fragments(lg)
-            fin = self.finish_stream('A', p) + self.finish_stream('B', p)
+            if self.fast:
+                fin = self.interleave(self.finish_fast('A', p), self.finish_fast('B', p, alt=True)) + self.tile_check()
+            else:
+                fin = self.finish_stream('A', p) + self.finish_stream('B', p)
             n = 2 * self.NKF
             gv = [g * n // 32 for g in DMA_GAPS_V][:self.PPW] if self.PPW == 4 else [1 * n // 16, 5 * n // 16]
             gk = [g * n // 32 for g in DMA_GAPS_K][:self.PPW] if self.PPW == 4 else [9 * n // 16, 13 * n // 16]
             dma = self.dma_plan(p, gv, gk)
             lg = self.run_phase(self.phase_qk, fin, lg, p=p, dma_at=dma, tail_vreads=p)
+            if self.fast:                      # the ending item's last tile: its check (VCC is tile_check's), then its sums into l before l is parked
+                self.fix_check(p)
+                park = self.lupd('A') + self.lupd('B') + park
             self.mask_keys(0, 0)
             self.tile0_diag(cond)
             self.run_phase(self.phase_pv, park + sta + unit, lg, p=p, dma_at={}, preissued=True)
@@ -1151,7 +1400,7 @@ class Gen:
         self.i("s_nop 7")
         self.i("s_nop 7")
         for X in "AB":
-            self.emit(self.start_stream(X, 0))
+            self.emit(self.start_fast(X, 0, with_max=True) if self.fast else self.start_stream(X, 0))
         for X in "AB":
             self.i(f"v_mov_b32 {vr(STV(X, 'al'))}, 1.0")
         self.i(f"s_mov_b64 {S('grow')}, 0")
@@ -1551,6 +1800,9 @@ class Gen:
             self.lane_constants_d128(L, T0, T1, T2, T3, W)
         else:
             self.lane_constants_d64(L, T0, T1, T2, T3, W)
+        if self.fast:
+            for X in "AB":
+                self.i(f"v_mov_b32 {vr(STV(X, 'thr'))}, 0x46800000")              # 2^14: the tile-sum limit of the fast loop (finish_fast)
         # -- first item: decode, fetch its Q block, K0, then V0 and K1
         self.i(f"s_mov_b32 {S('n_u')}, 0")
         self.i(f"s_mov_b32 {S('n_sub')}, 0")
@@ -1700,7 +1952,14 @@ class Gen:
             self.zero_o()
             self.item_switch()
             self.i(f"s_branch {lloop}")
+        assert not self.lstack and self.L is self.main
         self.main += self.ool
+        self.main += self.ool2
+        if self.fast:                          # the fix-up subroutines, behind every call site (fix_check adds a positive offset to its pc)
+            self.L = self.main
+            for b in (0, 1):
+                self.lab(f".L{n}_fixup{b}")
+                self.fixup(b)
         self.main += [f".L{n}_fend:", f"\t.size\t{n}, .L{n}_fend-{n}"]
 
     def descriptor(self):

@@ -289,8 +289,8 @@ int pfa_fa3_describe(const pfa_fa3_args* a, char* buf, size_t n) {
     const int st = check(a);
     if (st != PFA_OK) return st;
     if (a->dtype_in == PFA_DTYPE_FP32) {
-        if (buf && n) snprintf(buf, n, "fa3_fwd_f32_d%d_exact", a->D);
-        return ((a->Sq + 63) / 64) * a->B * a->H;
+        if (buf && n) snprintf(buf, n, "fa3_fwd_f32_mfma_d%d_exact", a->D);
+        return ((a->Sq + pfa::F32_BM - 1) / pfa::F32_BM) * a->B * a->H;
     }
     const Variant v = pick(a);
     if (buf && n) {
@@ -333,7 +333,7 @@ static int launch_f32(const pfa_fa3_args* a, void* stream) {
     }
     if (lds > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     void* kargs[] = {&p};
-    e = hipLaunchKernel(fn, dim3((unsigned)(((a->Sq + 63) / 64) * a->B * a->H)), dim3(256), kargs, (size_t)lds, (hipStream_t)stream);
+    e = hipLaunchKernel(fn, dim3((unsigned)(((a->Sq + pfa::F32_BM - 1) / pfa::F32_BM) * a->B * a->H)), dim3(256), kargs, (size_t)lds, (hipStream_t)stream);
     if (prev_dev != a->device_id) (void)hipSetDevice(prev_dev);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;

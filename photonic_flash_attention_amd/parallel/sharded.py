@@ -28,7 +28,80 @@ import torch
 import torch.distributed as dist
 
 GATHER_ALGO = "all_gather_into_tensor"
-GATHER_ALGOS = ("all_gather_into_tensor", "direct")
+GATHER_ALGOS = ("all_gather_into_tensor", "direct", "sdma")
+
+
+class PeerGather:
+    """The combine on the COPY ENGINES: every rank maps every peer's shard buffer into its own address space once (IPC handles of the
+    tensors' allocations, exchanged over the process group) and then PULLS the W-1 peer shards with W-1 asynchronous device-to-device
+    copies on W-1 streams -- SDMA transfers over the W-1 xGMI links of the rank, no kernel, no CU.  This is the only form of the gather
+    that can run beside the persistent forward, which holds a workgroup (and all 160 KiB of LDS) on every CU for the whole launch: an
+    RCCL kernel enqueued beside it only runs when it drains (or on the CUs `pfa_fa3_args.reserve_cus` leaves free).
+
+    One process per GPU, all GPUs of the node visible to every process (a launcher that hides the peers' devices makes peer mapping
+    impossible: the constructor raises, and callers fall back to the collectives).  `src` must be the SAME tensor (same allocation) at
+    every call: its handle is exchanged once.  Peers must have finished writing their shard before `gather` reads it: `gather` begins
+    with a barrier of the process group (host side; the caller synchronises its compute stream first, or passes `ready` events)."""
+
+    def __init__(self, src: torch.Tensor, group=None):
+        from torch.multiprocessing.reductions import reduce_tensor
+        if not src.is_cuda or not src.is_contiguous():
+            raise ValueError("PeerGather needs a contiguous device tensor")
+        self.group, self.src = group, src
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        fn, args = reduce_tensor(src)                   # (rebuild_cuda_tensor, its arguments: IPC handle of the allocation + view geometry)
+        handles = [None] * self.world
+        dist.all_gather_object(handles, (fn, args), group=group)
+        self.peers, err = [], None
+        try:
+            for r, (f, a) in enumerate(handles):
+                self.peers.append(src if r == self.rank else f(*a))   # a tensor of this process that aliases rank r's shard
+        except Exception as exc:   # noqa: BLE001  (peer devices hidden from this process, IPC refused, ...)
+            err = f"{type(exc).__name__}: {exc}"
+        oks = [None] * self.world                       # all ranks agree: either every mapping worked or nobody uses this path
+        dist.all_gather_object(oks, err, group=group)
+        bad = [(r, e) for r, e in enumerate(oks) if e is not None]
+        if bad:
+            raise RuntimeError(f"PeerGather: peer mapping failed on rank {bad[0][0]}: {bad[0][1]}")
+        self.streams = [torch.cuda.Stream(device=src.device) for _ in range(self.world)]
+        self.flat = torch.empty((self.world * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        self.buf = self.flat.view((self.world,) + tuple(src.shape))
+
+    def gather(self, wait_for: Optional[torch.cuda.Event] = None) -> torch.Tensor:
+        """-> [W * B_l, ...] with every rank's shard; returns after the copies are ENQUEUED (their completion: `self.done`, an event per
+        peer stream; `finish()` waits for all of them)."""
+        dist.barrier(self.group)                        # every peer's shard is complete (each rank synchronised its stream before)
+        self.done = []
+        for d in range(self.world):
+            r = (self.rank + d) % self.world             # start with one's own shard, then the peers in ring order: W-1 links at once
+            st = self.streams[d]
+            if wait_for is not None:
+                st.wait_event(wait_for)
+            with torch.cuda.stream(st):
+                self.buf[r].copy_(self.peers[r], non_blocking=True)       # contiguous, same dtype: a plain hipMemcpyAsync (SDMA)
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self.done.append(ev)
+        return self.flat
+
+    def finish(self) -> None:
+        for ev in self.done:
+            ev.synchronize()
+        dist.barrier(self.group)                        # nobody overwrites its shard while a peer still reads it
+
+    def pull_after(self, ev: torch.cuda.Event):
+        """Device-side form for pipelined loops: the W copies, each on its stream behind `ev` (an event after which every rank's shard is
+        known to be complete, e.g. recorded behind a tiny all-reduce); -> the events of their completion."""
+        done = []
+        for d in range(self.world):
+            r, st = (self.rank + d) % self.world, self.streams[d]
+            st.wait_event(ev)
+            with torch.cuda.stream(st):
+                self.buf[r].copy_(self.peers[r], non_blocking=True)
+                e = torch.cuda.Event()
+                e.record(st)
+                done.append(e)
+        return done
 
 
 def _direct_gather(buf: torch.Tensor, src: torch.Tensor, group=None) -> None:
@@ -45,6 +118,20 @@ def _direct_gather(buf: torch.Tensor, src: torch.Tensor, group=None) -> None:
         ops.append(dist.P2POp(dist.irecv, buf[frm], frm if group is None else dist.get_global_rank(group, frm), group))
     for w in dist.batch_isend_irecv(ops):
         w.wait()
+
+
+_PEER_GATHERS: dict = {}
+
+
+def _peer_gather_for(src: torch.Tensor, group=None) -> "PeerGather":
+    """One PeerGather per shard buffer (its handles are exchanged once; every rank must call this for the same buffers in the same order)."""
+    key = (src.data_ptr(), tuple(src.shape), src.dtype, id(group))
+    pg = _PEER_GATHERS.get(key)
+    if pg is None:
+        if len(_PEER_GATHERS) >= 8:
+            _PEER_GATHERS.clear()
+        pg = _PEER_GATHERS[key] = PeerGather(src, group)
+    return pg
 
 
 def shard_plan(B: int, H: int, world: int) -> Tuple[str, int]:
@@ -82,7 +169,13 @@ def gather_outputs(out_local: torch.Tensor, plan: Tuple[str, int] = ("batch", 0)
     if src.is_cuda:
         torch.cuda.synchronize(src.device)
         t0 = time.perf_counter()
-    if algo == "direct":
+    if algo == "sdma":
+        pg = _peer_gather_for(src, group)
+        t0 = time.perf_counter()                        # (the one-time handle exchange is not part of a gather)
+        flat = pg.gather()
+        pg.finish()
+        buf = flat.view((world,) + tuple(src.shape))
+    elif algo == "direct":
         _direct_gather(buf, src, group)
     else:
         dist.all_gather_into_tensor(flat, src, group=group)
@@ -159,6 +252,8 @@ def overlapped_forward_gather(step: Callable[[], None], out_local: torch.Tensor,
                 dist.all_gather_into_tensor(flat, out_local.contiguous(), group=group)
         dist.barrier(group)
         return (time.perf_counter() - t0) * 1e3 / steps
+    if algo == "sdma":
+        return _overlapped_sdma(step, out_local, steps, group)
     comm = torch.cuda.Stream(device=dev)
     bufs = [torch.empty((world * out_local.shape[0],) + tuple(out_local.shape[1:]), dtype=out_local.dtype, device=dev)
             for _ in range(2)]
@@ -184,6 +279,47 @@ def overlapped_forward_gather(step: Callable[[], None], out_local: torch.Tensor,
                 dist.all_gather_into_tensor(bufs[s], stage[s], group=group)
             done[s] = torch.cuda.Event()
             done[s].record(comm)
+    torch.cuda.synchronize(dev)
+    dist.barrier(group)
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) * 1e3 / steps
+
+
+def _overlapped_sdma(step: Callable[[], None], out_local: torch.Tensor, steps: int, group=None) -> float:
+    """One copy-engine gather per forward, overlapped with the next forward.  Per step j (stage s = j & 1), without any host wait:
+    all-reduce A (one element, comm stream, behind this rank's copies of step j - 2): every rank has finished READING stage s -> the
+    forward's output is copied into stage s; all-reduce B behind that: every rank's stage s is complete -> the W pulls start, on W
+    streams, and run beside forward j + 1.  The two all-reduces are tiny RCCL kernels: beside a forward that holds every CU they run
+    when it drains, i.e. exactly when their condition is met anyway."""
+    dev = out_local.device
+    stage = [torch.empty_like(out_local) for _ in range(2)]
+    pgs = [PeerGather(st, group) for st in stage]
+    flag = torch.zeros(1, device=dev)
+    comm = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    done = [[], []]
+    dist.barrier(group)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for j in range(steps):
+        s = j & 1
+        step()
+        with torch.cuda.stream(comm):
+            for e in done[s]:
+                comm.wait_event(e)
+            dist.all_reduce(flag, group=group)                      # A: nobody still reads stage s
+            free = torch.cuda.Event()
+            free.record(comm)
+        main.wait_event(free)
+        stage[s].copy_(out_local, non_blocking=True)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(comm):
+            comm.wait_event(ready)
+            dist.all_reduce(flag, group=group)                      # B: every rank's stage s is complete
+            go = torch.cuda.Event()
+            go.record(comm)
+        done[s] = pgs[s].pull_after(go)
     torch.cuda.synchronize(dev)
     dist.barrier(group)
     torch.cuda.synchronize(dev)

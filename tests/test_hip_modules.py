@@ -106,7 +106,7 @@ def test_module_forward_matches_reference_module_golden():
     print(f"fp32 module, bf16 attention operands (opt-in): max-abs {errb:.3e}")
     assert err < errb <= 3e-2
     q = torch.zeros(1, 2, 64, 64, device=DEV)
-    assert _capi.describe(ops.build_args(q, q, q, torch.empty_like(q))[0])[0] == "fa3_fwd_f32_d64_exact"
+    assert _capi.describe(ops.build_args(q, q, q, torch.empty_like(q))[0])[0] == "fa3_fwd_f32_mfma_d64_exact"
 
 
 @pytest.mark.parametrize("case", [(2, 3, 130, 257, 64, True, None), (1, 2, 300, 300, 128, True, [211]), (2, 2, 64, 1000, 128, False, [1000, 3]),

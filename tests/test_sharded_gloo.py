@@ -94,10 +94,18 @@ def _worker_masks(rank, world, port, q_out):
             def compute(a, b_, c, causal=False, key_mask=None, mask=None):
                 seen.append((tuple(a.shape), None if key_mask is None else tuple(key_mask.shape), None if mask is None else tuple(mask.shape)))
                 mm = mask if mask is not None else key_mask[:, None, None, :]
+                if mm.dim() == 3:
+                    mm = mm[:, None]
                 return orc.flash_attention_forward(a.permute(0, 2, 1, 3).float(), b_.permute(0, 2, 1, 3).float(), c.permute(0, 2, 1, 3).float(),
                                                    mm, D ** -0.5).permute(0, 2, 1, 3)
 
-            for algo in sharded.GATHER_ALGOS:
+            m3 = m4[:, 0].contiguous()                                           # a 3-D [B,Sq,Sk] mask follows the batch plan too
+            out3 = sharded.sharded_attention(q, k, v, compute=compute, mask=m3)
+            assert float((out3 - compute(q, k, v, mask=m3)).abs().max()) <= 1e-6 and seen[0][2][0] == (B // world if B % world == 0 else B)
+            seen.clear()
+            with pytest.raises(ValueError):                                      # the copy-engine gather maps DEVICE buffers of the peers
+                sharded.gather_outputs(q, sharded.shard_plan(B, H, world), algo="sdma")
+            for algo in (a_ for a_ in sharded.GATHER_ALGOS if a_ != "sdma"):
                 plan = sharded.shard_plan(B, H, world)
                 out_l = sharded.sharded_attention(q, k, v, compute=compute, key_mask=km, gather=False)
                 full_k = sharded.gather_outputs(out_l, plan, algo=algo)

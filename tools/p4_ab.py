@@ -118,6 +118,19 @@ def stamp_report(name, dbg, grid):
     print(f"  {name}: kernel cycles per wave mean {tot.mean():.0f} (min {tot.min():.0f} max {tot.max():.0f}); in-kernel clock {clk.mean():.3f} GHz; "
           f"wall per wave {wall.mean():.1f} us (max {wall.max():.1f}, max/mean {wall.max() / wall.mean():.3f})")
     print("     wall by workgroup % 8: " + " ".join(f"{wall[x::8].mean().item():.1f}" for x in range(8)))
+    xcc = (d[:, 0, 14].long() & 15)                     # HW_REG_XCC_ID as read by wave 0 of every workgroup
+    hw = d[:, 0, 15].long()
+    tab = [[int(((xcc == x) & (torch.arange(grid) % 8 == m)).sum()) for x in range(8)] for m in range(8)]
+    print("     workgroup % 8 -> XCC id histogram (rows: wg % 8, columns: XCC 0..7): " + " | ".join(" ".join(str(c) for c in row) for row in tab))
+    cu = ((hw >> 8) & 15) + 16 * ((hw >> 12) & 1) + 32 * ((hw >> 13) & 7)      # CU_ID, SH_ID, SE_ID of HW_ID
+    pairs = {}
+    for w in range(grid):
+        pairs.setdefault((int(xcc[w]), int(cu[w])), []).append(w)
+    dup = {k: v for k, v in pairs.items() if len(v) > 1}
+    print(f"     distinct (XCC, SE/SH/CU) places: {len(pairs)} for {grid} workgroups; places holding more than one workgroup: {len(dup)}"
+          + (f" e.g. {list(dup.items())[:3]}" if dup else ""))
+    by_xcc = [wall[(xcc == x).nonzero().flatten()].mean().item() if int((xcc == x).sum()) else float('nan') for x in range(8)]
+    print("     wall by XCC id: " + " ".join(f"{v:.1f}" for v in by_xcc))
     if nfull > 0:
         print(f"     per FULL iteration: QK^T {acc[..., 0].sum() / nfull:.0f}  PV {acc[..., 1].sum() / nfull:.0f}  sync+bookkeeping {acc[..., 2].sum() / nfull:.0f}"
               f"  (vmcnt {acc[..., 9].sum() / nfull:.0f}, barrier {acc[..., 12].sum() / nfull:.0f});  per item: switch+prologue {acc[..., 3].sum() / nitems:.0f}"
@@ -176,7 +189,8 @@ def main():
                 d0 = float((o.float() - o0.float()).abs().nan_to_num(1e9).max())
                 dr = float((o.float() - ref.float()).abs().nan_to_num(1e9).max())
                 dl = float((l - rlse).abs().nan_to_num(1e9).max())
-                ok = nan == 0 and dr <= (3e-5 if a.parity else 2e-2) and dl <= 1e-4
+                scale = max(1.0, float(ref.float().abs().max()) / 4)          # (spiked inputs: the outputs and their half ulps grow with them)
+                ok = nan == 0 and dr <= (3e-5 if a.parity else 2e-2) * scale and dl <= 1e-4 * scale
                 bad += 0 if ok else 1
                 print(f"  {vr.name:14s} nan {nan}  bitwise-equal to {variants[0].name}: {same * 100:.4f} %  max|d| vs {variants[0].name} {d0:.3e}  "
                       f"vs 8-wave kernel {dr:.3e}  LSE {dl:.3e}  {'ok' if ok else 'MISMATCH'}", flush=True)
