@@ -154,9 +154,10 @@ V_TA = 254            # causal: r + 1 - 4h (element-mask threshold of the diagon
 V_LANE = 255
 V_E = list(range(0, 16))   # prologue / epilogue / rescale scratch (v0 = workitem id at entry)
 STAMP = int(knob("P4_STAMP", "0"))      # 1: every phase; 2: one stamp per iteration only (buckets 0 / 1 stay empty); 3: kernel totals only (lean loop and pipelined seam stay on)
-MB = int(knob("P4_MB", "0"))              # fast loop: the iteration's barrier sits INSIDE the PV phase (behind the last V^T read), and the first K fragments of the
+MB = int(knob("P4_MB", "1"))              # fast loop: the iteration's barrier sits INSIDE the PV phase (behind the last V^T read), and the first K fragments of the
                                           # next QK^T phase are requested right behind it -- their latency and the barrier skew run under the rest of PV(j)
-MBGAP = int(knob("P4_MBGAP", "20"))       # ... behind this MFMA gap of 32 (scaled for D = 64)
+MBGAP = int(knob("P4_MBGAP", "0"))        # ... behind this MFMA gap of the PV phase (0: 27 of 32 at D = 128, 12 of 16 at D = 64 -- same box, gaps 16..27 / 8..13:
+                                          # the late barrier is worth +0.4..1 % over gap 20 at D = 128; at D = 64 gap 13 loses 2 %)
 DIET = int(knob("P4_DIET", "1"))          # fast loop: block sums start with t0 + t1 (no zeroing), one compare + s_cbranch_vccnz per tile for both strips
 FASTMAX = int(knob("P4_FASTMAX", "1"))    # the tile loop without a row max (Gen.fast; see finish_fast): a tile's exponentials are taken against the running
                                           # maximum, its scaled scores stay in the S buffer, and a row sum past 2^14 sends the wave to a fix-up subroutine
@@ -222,7 +223,7 @@ class Gen:
         self.mwords = kmask or (klen and not causal)
         # fast: the plain kernels of the fast variant -- every row sees a key in its item's tile 0 (so its maximum is finite from there on)
         self.fast = bool(FASTMAX) and not split and not kmask and not klen
-        self.mb = self.fast and bool(MB) and not STAMP
+        self.mb = self.fast and bool(MB) and not STAMP      # (on the parity variant's SAFE bodies it buys nothing at D = 128 and costs 4 % at D = 64)
         assert not (kmask and STAMP), "the key-mask kernels keep their mask words where the stamps keep their clock (s[58:59], the dbg kernarg)"
         assert D in (64, 128)
         self.D, self.KS, self.DB = D, D // 16, D // 32                 # head dim, k-steps of QK^T, 32-wide d blocks of PV
@@ -734,7 +735,8 @@ class Gen:
             i, X = hs // 2, 'AB'[hs % 2]
             mark = len(self.L)
             if hs % 2 == 0 and i % WAITN == 0:
-                w = lg.need([('k', i + x) for x in range(WAITN)])
+                # (seam: the successor's Q fragments are in flight too -- older than the K reads, or, in the mid-barrier loop, younger)
+                w = lg.need([('k', i + x) for x in range(WAITN)] + [('q', Y, i + x) for Y in "AB" for x in range(WAITN)])
                 if w:
                     self.i(w)
             self.i(self.qk_mfma(nb, X, i))
@@ -1019,7 +1021,7 @@ class Gen:
                 inline = [f"s_add_u32 {S('koff')}, {S('koff')}, {S('ktile')}", f"s_add_u32 {S('voff')}, {S('voff')}, {S('vtile')}", "s_waitcnt vmcnt(0)"]
             else:
                 inline = self.capture(lambda: self.stream_bottom(p, barrier=False))
-            mid = dict(gap=MBGAP * 2 * self.NVF // 32, inline=inline, kreads=self.kprefetch(p))
+            mid = dict(gap=MBGAP or (27 if self.D == 128 else 12), inline=inline, kreads=self.kprefetch(p))
         self.run_phase(self.phase_pv, sta, lg, p=p, dma_at={}, preissued=True, mid=mid)
         self.abl_on = False
         self.stamp(1, count=7)
@@ -1861,6 +1863,8 @@ class Gen:
         self.item_prologue()
         self.i("s_waitcnt vmcnt(0)")
         self.i("s_barrier")                    # V0 / K1 published; every wave is done with K slot 0
+        if self.mb:
+            self.emit(self.kprefetch(1))       # the loop's first iteration (parity 0) reads K(1) from slot 1
         self.stamp(3, count=8)
         # ---- tile loop, unrolled by the two S buffers ----------------------------------------------------------------------------------
         lloop, lgen = f".L{n}_loop", f".L{n}_generic"
@@ -1879,6 +1883,8 @@ class Gen:
                 if self.kmask:
                     self.emit(self.mask_load())
                 self.body_full(p, lean=True)
+                if self.mb:                         # (offsets, counted wait and barrier sit inside the body's PV phase)
+                    continue
                 self.i(f"s_add_u32 {S('koff')}, {S('koff')}, {S('ktile')}")
                 self.i(f"s_add_u32 {S('voff')}, {S('voff')}, {S('vtile')}")
                 if self.kmask:
@@ -1913,15 +1919,22 @@ class Gen:
             self.i(f"s_cbranch_scc0 {lnf}")
             self.body_full(p)
             self.lab(ld)
-            self.stream_bottom(p)
+            if not self.mb:
+                self.stream_bottom(p)
             self.out_of_line(True)
             self.lab(lnf)
             self.i(f"s_cmp_eq_u32 {S('wrem')}, 0")
             self.i(f"s_cbranch_scc1 {ll}")
             self.body_skip(p)
+            if self.mb:                             # (no PV phase to carry the barrier: at the end, the K fragments of the next iteration behind it)
+                self.stream_bottom(p)
+                self.emit(self.kprefetch(p))
             self.i(f"s_branch {ld}")
             self.lab(ll)
             self.body_last(p)
+            if self.mb:
+                self.stream_bottom(p)
+                self.emit(self.kprefetch(p))
             self.i(f"s_branch {ld}")
             self.out_of_line(False)
         self.i(f"s_sub_u32 {S('irem')}, {S('irem')}, 2")
@@ -1948,6 +1961,8 @@ class Gen:
             self.body_seam(False)
             self.lab(lsd)
             self.stream_bottom(1)
+            if self.mb:
+                self.emit(self.kprefetch(1))   # the next item's iteration 0 (parity 0) reads K_next(1) from slot 1
             self.item_epilogue(saved=True)
             self.zero_o()
             self.item_switch()

@@ -116,12 +116,10 @@ Variant pick(const pfa_fa3_args* a) {
     // +24 %, S2048 causal +12 %: profiles/r02_p4_experiments.txt); the 4-wave HIP kernel keeps the other long problems.
     if (pfa::p4_eligible(a) && (var == 45 || var == 0)) {
         Variant v = p4_variant(a, causal);
-        // D = 64: the tile loop is bound by the softmax's vector instructions (half the MFMA work under the same exponentials), where
-        // two waves per SIMD (the 8-wave HIP kernel) overlap better than one: the persistent kernel only wins while every unit has a CU
-        // of its own, i.e. no item seam (same box: C2 +3 %, 256 units +2 %; 384 units -9 %, 1024 units -8 %).  Selector 45 forces it.
-        const int64_t nbq = ((int64_t)a->Sq + 255) / 256, units = (int64_t)a->B * a->H * (causal ? (nbq + 1) / 2 : nbq);
-        const bool take = a->D == 128 || var == 45 || units <= v.p4_grid;
-        if (v.p4_grid > 0 && take) return v;   // (0: the code object did not load on this device -- fall through to the HIP kernels)
+        // D = 64 too since round 3: with the fast loop (no row max) and the mid-phase barrier the persistent kernel beats the 8-wave HIP kernel
+        // on every D = 64 shape tried, also with several units per CU (same box, selector 44 -> 45: C2 527 -> 615 TFLOP/s, B16 H16 S2048 922 ->
+        // 1000, B4 H12 S2048 causal 599 -> 681, B4 H16 S4096 causal 904 -> 925: profiles/r03_p4_experiments.txt).
+        if (v.p4_grid > 0) return v;   // (0: the code object did not load on this device -- fall through to the HIP kernels)
     }
     if (w4_ok && (var == 43 || ((var == 0 || var == 45) && avg_tiles >= 16))) return w4_variant(a, causal, out32);
     return a->dtype_in == PFA_DTYPE_BF16 ? by_d<__bf16>(a->D, causal, split, kmask, out32, "bf16")
