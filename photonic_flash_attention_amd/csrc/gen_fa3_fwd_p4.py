@@ -154,6 +154,7 @@ V_TA = 254            # causal: r + 1 - 4h (element-mask threshold of the diagon
 V_LANE = 255
 V_E = list(range(0, 16))   # prologue / epilogue / rescale scratch (v0 = workitem id at entry)
 STAMP = int(knob("P4_STAMP", "0"))      # 1: every phase; 2: one stamp per iteration only (buckets 0 / 1 stay empty); 3: kernel totals only (lean loop and pipelined seam stay on)
+LIGHT1 = int(knob("P4_LIGHT1", "0"))      # EXPERIMENT: causal units run their light block first (the heavy streams of a head then follow each other within 28 tiles)
 MB = int(knob("P4_MB", "1"))              # fast loop: the iteration's barrier sits INSIDE the PV phase (behind the last V^T read), and the first K fragments of the
                                           # next QK^T phase are requested right behind it -- their latency and the barrier skew run under the rest of PV(j)
 MBGAP = int(knob("P4_MBGAP", "0"))        # ... behind this MFMA gap of the PV phase (0: 27 of 32 at D = 128, 12 of 16 at D = 64 -- same box, gaps 16..27 / 8..13:
@@ -1133,8 +1134,8 @@ class Gen:
         if self.causal:
             self.i(f"s_sub_u32 {t3}, {ka('NB')}, 1")
             self.i(f"s_sub_u32 {t3}, {t3}, {t1}")                      # heavy block NB-1-p
-            self.i(f"s_cmp_eq_u32 {S('n_sub')}, 0")
-            self.i(f"s_cselect_b32 {t1}, {t3}, {t1}")                  # qblk
+            self.i(f"s_cmp_eq_u32 {S('n_sub')}, {1 if LIGHT1 else 0}")
+            self.i(f"s_cselect_b32 {t1}, {t3}, {t1}")                  # qblk (LIGHT1: a unit's light block first, then its heavy one)
             self.i(f"s_add_u32 {t3}, {t1}, 1")
             self.i(f"s_lshl_b32 {S('n_nt')}, {t3}, 2")                 # nt = 4 (qblk + 1)
         else:

@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--parity", action="store_true", help="the fp32-store + split-P kernels")
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--layout", default="bshd", help="memory layout of q / k / v / out: bshd (what a fused projection yields) or bhsd (head-major)")
     ap.add_argument("--spike", type=float, default=0.0, help="--check: scale some key rows by this factor (forces online-softmax rescales)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -160,7 +161,10 @@ def main():
     for sname in a.shapes.split(","):
         B, H, S, D, causal = SHAPES[sname]
         g = torch.Generator(device=dev).manual_seed(1234)
-        q, k, v = (torch.randn(B, S, H, D, device=dev, dtype=torch.float32, generator=g).to(dt).permute(0, 2, 1, 3) for _ in range(3))
+        if a.layout == "bhsd":
+            q, k, v = (torch.randn(B, H, S, D, device=dev, dtype=torch.float32, generator=g).to(dt) for _ in range(3))
+        else:
+            q, k, v = (torch.randn(B, S, H, D, device=dev, dtype=torch.float32, generator=g).to(dt).permute(0, 2, 1, 3) for _ in range(3))
         if a.spike:
             kk = k.permute(0, 2, 1, 3)
             kk[:, S // 3::S // 7] *= a.spike               # a few keys far out: row maxima jump mid-item
@@ -170,7 +174,8 @@ def main():
         outs = []
         print(f"== {sname}: B{B} H{H} S{S} D{D} {'causal' if causal else 'full'}  {kn}", flush=True)
         for vr in variants:
-            out = torch.full((B, S, H, D), float("nan"), device=dev, dtype=odt).permute(0, 2, 1, 3)
+            out = torch.full((B, H, S, D), float("nan"), device=dev, dtype=odt) if a.layout == "bhsd" else \
+                torch.full((B, S, H, D), float("nan"), device=dev, dtype=odt).permute(0, 2, 1, 3)
             lse = torch.full((B, H, S), float("nan"), device=dev, dtype=torch.float32)
             dbg = torch.zeros(n_cu * 4 * 16, dtype=torch.int32, device=dev) if a.stamp else None
             buf, grid = kernargs(q, k, v, out, lse, causal, n_cu, dbg=dbg)
