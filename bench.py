@@ -385,6 +385,24 @@ def main():
                            "kernel": _capi.describe(ops.build_args(q2v, k2v, v2v, o2v, causal=False, **kw)[0])[0],
                            "shape": f"B={b2} S={s2} H={h2} D={d2} non-causal" + (", key-padding mask (lengths in [S/2, S], dense-equivalent flops)" if kw else "")}
         del q2, k2, v2, o2
+        # the padded decoder batch: C3's shape under the causal mask with per-batch key counts (seqlens_k, lengths in [S/2, S]) -- round 3:
+        # on the persistent ragged kernels, a block behind its batch's cut runs only the key groups that hold visible keys
+        b2, h2, s2, d2, c2, _w = WORKLOADS["C3"]
+        q2, k2, v2, o2 = make(b2, h2, s2, d2, 80)
+        q2v, k2v, v2v, o2v = (t.permute(0, 2, 1, 3) for t in (q2, k2, v2, o2))
+        lens3 = [s2, s2 * 9 // 16, s2 * 13 // 16, s2 * 11 // 16][:b2] + [s2 * 3 // 4] * max(0, b2 - 4)
+        sl3 = torch.tensor(lens3, dtype=torch.int32, device=dev)
+
+        def step5():
+            ops.fa3_forward(q2v, k2v, v2v, causal=True, seqlens_k=sl3, out=o2v)
+        for _ in range(100):
+            step5()
+        w5, kk5 = timed(step5, args.steps, 3)
+        m5 = statistics.median(kk5)
+        others["C3_seqlens"] = {"ms": round(m5, 4), "tflops": round(flops(b2, h2, s2, d2, True) / (m5 * 1e-3) / 1e12, 2), "frac": None,
+                                "kernel": _capi.describe(ops.build_args(q2v, k2v, v2v, o2v, causal=True, seqlens_k=sl3)[0])[0],
+                                "shape": f"C3 with seqlens_k = {lens3} under the causal mask (dense-equivalent flops: the padding is not computed)"}
+        del q2, k2, v2, o2
 
     # ---- 4. backward (pfa_fa3_bwd: the reference trains through autograd over its eager core, tests/unit/test_flash_attention_3.py:137-160)
     # and the module level (projections + core, core/flash_attention_3.py:49-118), same workload, same process

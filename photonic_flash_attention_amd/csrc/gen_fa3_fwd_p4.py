@@ -169,6 +169,7 @@ ABL = knob("P4_ABL", "")                                         # timing-only a
 DMA_PRICE = int(knob("P4_DMA_PRICE", "30"))                      # issue cycles budgeted for one LDS-DMA piece
 DMA_GAPS_V = [int(x) for x in knob("P4_DMA_GAPS_V", "1,5,9,13").split(",")]      # QK^T gaps that carry the V(j+1) pieces
 DMA_GAPS_K = [int(x) for x in knob("P4_DMA_GAPS_K", "17,21,25,27").split(",")]   # ... and the K(j+2) pieces
+NODIAG = "0x40000000"      # causal ragged kernels, nd_n / nd: the item has no diagonal tile (it lies behind its batch's seqlens_k cut)
 NEG_BIG = "0xf149f2ca"     # -1e30f
 NEG_INF = "0xff800000"
 
@@ -221,10 +222,12 @@ class Gen:
         # otherwise -- the causal kernels' sub-item flag without the causal mask, the seqlens register (non-causal only) with it --
         # and start an item at the keys its batch has (seqlens_k; Sk without it, and always under the causal mask)
         self.kleft, self.kleft0 = (S('L_n'), ka('Sk')) if causal else (S('n_sub'), S('L_n'))
-        self.mwords = kmask or (klen and not causal)
+        self.mwords = kmask or klen            # (causal ragged kernels: the words carry seqlens_k; without it they are all ones where a row can look)
+        self.nd_n, self.nd = ka('dbg'), ka('dbg', hi=True)     # (ragged kernels: the `dbg` kernarg pair is theirs -- no stamps, no mask bytes)
+        self.cl = klen and causal              # seqlens_k under the causal mask: an item's tile count is cut to its batch's keys (decode)
         # fast: the plain kernels of the fast variant -- every row sees a key in its item's tile 0 (so its maximum is finite from there on)
         self.fast = bool(FASTMAX) and not split and not kmask and not klen
-        self.mb = self.fast and bool(MB) and not STAMP      # (on the parity variant's SAFE bodies it buys nothing at D = 128 and costs 4 % at D = 64)
+        self.mb = self.fast and bool(MB) and STAMP in (0, 3)      # (on the parity variant's SAFE bodies it buys nothing at D = 128 and costs 4 % at D = 64)
         assert not (kmask and STAMP), "the key-mask kernels keep their mask words where the stamps keep their clock (s[58:59], the dbg kernarg)"
         assert D in (64, 128)
         self.D, self.KS, self.DB = D, D // 16, D // 32                 # head dim, k-steps of QK^T, 32-wide d blocks of PV
@@ -846,7 +849,7 @@ class Gen:
         if self.kmask:                                                  # ... and so are its mask bytes: row n_b
             self.i(f"s_mul_i32 {ka('pad')}, {S('n_b')}, {ka('Sk')}")
             self.i(f"s_mov_b32 {self.kleft}, {self.kleft0}")             # ... and the keys its batch has
-        if self.klen and not self.causal:
+        if self.klen:
             self.i(f"s_mov_b32 {ka('pad')}, {S('L_n')}")                 # keys left from tile j+2 on
         self.lab(l1)
         if self.kmask:                                                  # the bytes of tile j+2 (its K pieces go to slot p in this iteration),
@@ -854,7 +857,7 @@ class Gen:
             self.i(f"s_mov_b64 exec, {S('t2')}")
             self.emit(self.mask_load())
             self.i("s_mov_b64 exec, -1")
-        if self.klen and not self.causal:
+        if self.klen:
             self.len_word(p)                                            # the word of tile j+2 from the keys left
         self.i(f"s_cmp_lg_u32 {S('vrem')}, 0")
         self.i(f"s_cbranch_scc1 {l2}")
@@ -881,7 +884,7 @@ class Gen:
         self.i(f"s_sub_u32 {S('wrem')}, {S('wrem')}, 1")
         if self.kmask:
             self.i(f"s_add_u32 {ka('pad')}, {ka('pad')}, 64")
-        if self.klen and not self.causal:
+        if self.klen:
             self.i(f"s_sub_u32 {ka('pad')}, {ka('pad')}, 64")
         self.i(f"s_cmp_lg_u32 {S('qrem')}, 0")
         self.i(f"s_cbranch_scc1 {lq}")
@@ -1001,7 +1004,7 @@ class Gen:
             self.mask_keys(1 - p, 1 - p)       # tile j+1: buffer 1-p, word MK((j+1) & 1)
         if self.causal and not lean:           # the diagonal tile of this wave is tile wnt-1 = j+1  <=>  wrem == 1
             lm, lr = self.ul("mask"), self.ul("masked")
-            self.i(f"s_cmp_eq_u32 {S('wrem')}, 1")
+            self.i(f"s_cmp_eq_u32 {S('wrem')}, {self.nd if self.cl else 1}")
             self.i(f"s_cbranch_scc1 {lm}")
             self.lab(lr)
             self.out_of_line(True)
@@ -1207,6 +1210,33 @@ class Gen:
             self.i(f"s_max_u32 {t0}, {t0}, 4")
             self.i(f"s_min_u32 {S('n_nt')}, {t0}, {ka('nt_full')}")
             self.lab(lno)
+        if self.cl:
+            # seqlens_k under the causal mask (the padded decoder batch): with L = clamp(seqlens_k[b], 0, Sk) keys and G = max(1, ceil(L / 256))
+            # 256-key groups holding any of them, block qblk either keeps its diagonal (qblk + 1 <= G: the causal item as ever, the
+            # length words mask what lies past L inside its last group) or lies wholly behind the cut (qblk + 1 > G): then it runs the 4 G
+            # tiles of those groups like a non-causal item -- every wave the same tiles, no diagonal (nd_n = NODIAG).  Nothing past the
+            # group of the last visible key is fetched or computed.
+            lno = self.ul("noseqlens")
+            self.i(f"s_mov_b32 {S('L_n')}, {ka('Sk')}")
+            self.i(f"s_mov_b32 {self.nd_n}, 0")
+            self.i(f"s_load_dwordx2 {S('t2')}, s[0:1], {4 * KA_SEQLENS}")
+            self.i("s_waitcnt lgkmcnt(0)")
+            self.i(f"s_cmp_eq_u64 {S('t2')}, 0")
+            self.i(f"s_cbranch_scc1 {lno}")
+            self.i(f"s_lshl_b32 {t0}, {S('n_b')}, 2")
+            self.i(f"s_load_dword {t0}, {S('t2')}, {t0}")
+            self.i("s_waitcnt lgkmcnt(0)")
+            self.i(f"s_max_i32 {t0}, {t0}, 0")
+            self.i(f"s_min_i32 {S('L_n')}, {t0}, {ka('Sk')}")
+            self.i(f"s_add_u32 {t0}, {S('L_n')}, 255")
+            self.i(f"s_lshr_b32 {t0}, {t0}, 8")
+            self.i(f"s_max_u32 {t0}, {t0}, 1")                          # G
+            self.i(f"s_add_u32 {t1}, {S('n_qblk')}, 1")
+            self.i(f"s_cmp_gt_u32 {t1}, {t0}")
+            self.i(f"s_cselect_b32 {self.nd_n}, {NODIAG}, 0")
+            self.i(f"s_min_u32 {t0}, {t0}, {t1}")
+            self.i(f"s_lshl_b32 {S('n_nt')}, {t0}, 2")
+            self.lab(lno)
         self.lab(ln)
 
     def block_records(self, dst, qblk, ss, row_bytes, tmp):
@@ -1347,7 +1377,8 @@ class Gen:
             sta = self.start_stream('A', 0) + self.start_stream('B', 0)
         unit = [f"v_mov_b32 {vr(STV(X, 'al'))}, 1.0" for X in "AB"]
         # tile 0 of the successor is this wave's diagonal tile iff its tile count is 1: nt_n - 3 + wave == 1
-        cond = [f"s_add_u32 {S('t0')}, {S('nt_n')}, {S('wave')}", f"s_cmp_eq_u32 {S('t0')}, 4"]
+        cond = [f"s_add_u32 {S('t0')}, {S('nt_n')}, {S('wave')}"] + ([f"s_add_u32 {S('t0')}, {S('t0')}, {self.nd_n}"] if self.cl else []) + \
+               [f"s_cmp_eq_u32 {S('t0')}, 4"]
         lg = self.kprefetch_lg() if self.mb else Lgkm()      # (mid-barrier loop: K_next(0)'s first fragments were requested an iteration ago)
         if full:
             self.abl_on = True
@@ -1724,7 +1755,13 @@ class Gen:
         self.i(f"s_mov_b32 {S('irem')}, {S('n_nt')}")
         self.i(f"s_sub_u32 {S('krem')}, {S('n_nt')}, 2")
         self.i(f"s_sub_u32 {S('vrem')}, {S('n_nt')}, 1")
-        if self.causal:
+        if self.cl:                            # behind the cut every wave runs every tile (wnt = nt); `nd` = what wrem equals one iteration before the diagonal tile
+            self.i(f"s_cmp_eq_u32 {self.nd_n}, 0")
+            self.i(f"s_cselect_b32 {S('wrem')}, {S('wave')}, 3")
+            self.i(f"s_cselect_b32 {self.nd}, 1, 0x80000000")
+            self.i(f"s_add_u32 {S('wrem')}, {S('wrem')}, {S('n_nt')}")
+            self.i(f"s_sub_u32 {S('wrem')}, {S('wrem')}, 4")
+        elif self.causal:
             self.i(f"s_add_u32 {S('wrem')}, {S('n_nt')}, {S('wave')}")
             self.i(f"s_sub_u32 {S('wrem')}, {S('wrem')}, 4")                      # wnt - 1 = nt - 4 + wave
         else:
@@ -1822,7 +1859,7 @@ class Gen:
             self.i(f"s_add_u32 {ka('pad')}, {ka('pad')}, 64")
             self.emit(self.mask_load(1))
             self.i(f"s_add_u32 {ka('pad')}, {ka('pad')}, 64")                     # next: tile 2
-        if self.klen and not self.causal:      # the words of tiles 0 and 1; keys left from tile 2 on
+        if self.klen:      # the words of tiles 0 and 1; keys left from tile 2 on
             self.i(f"s_mov_b32 {ka('pad')}, {S('L_n')}")
             self.len_word(0)
             self.i(f"s_sub_u32 {ka('pad')}, {ka('pad')}, 64")
@@ -1876,7 +1913,7 @@ class Gen:
             # bodies without a diagonal tile (wrem = krem - 2 + wave >= 3).  A lean iteration issues the same DMA pieces and meets the
             # same barriers as a generic one, so every wave decides for itself.  (17 scalar instructions a tile were ~9 % of it.)
             # (lengths: tiles j+2, j+3 whole too; a causal item's last block may run three tiles past the keys: its mask bytes)
-            self.i(f"s_cmp_lt_u32 {S('krem')}, {(7 if self.kmask else 5) if self.causal else (4 if (self.klen or self.kmask) else 2)}")
+            self.i(f"s_cmp_lt_u32 {S('krem')}, {(7 if (self.kmask or self.klen) else 5) if self.causal else (4 if (self.klen or self.kmask) else 2)}")
             self.i(f"s_cbranch_scc1 {lgen}")
             self.i(f"s_cmp_lg_u32 {S('qrem')}, 0")
             self.i(f"s_cbranch_scc1 {lgen}")
@@ -1898,7 +1935,7 @@ class Gen:
                 self.i(f"s_sub_u32 {S(c)}, {S(c)}, 2")
             if self.kmask:                          # (their words need no length: all keys exist)
                 self.i(f"s_sub_u32 {self.kleft}, {self.kleft}, 128")
-            if self.klen and not self.causal:       # the words of tiles j+2, j+3 (all keys exist), the keys left behind them
+            if self.klen:       # the words of tiles j+2, j+3 (all keys exist), the keys left behind them
                 self.i(f"s_mov_b64 {self.MK(0)}, -1")
                 self.i(f"s_mov_b64 {self.MK(1)}, -1")
                 self.i(f"s_sub_u32 {ka('pad')}, {ka('pad')}, 128")

@@ -140,13 +140,14 @@ int p4_flavour(const pfa_fa3_args* a) {
 // Shapes the persistent kernel takes (everything else stays on the HIP kernels): D = 128 or 64; the fast variant (one P operand, 16-bit
 // store) or the parity variant (split P AND fp32 store); no element mask; Sq >= 128 and Sk >= 193 of any length (ragged: *_kl_*); a
 // [B, Sk] key mask with contiguous rows on whole blocks / tile pairs (*_km_*: the kernel reads the bytes itself); seqlens_k without the
-// causal mask (an item's tile count is cut to its batch's keys); under the causal mask Sq == Sk (units are heavy + light block pairs,
-// with an odd block count the middle block is a unit of its own).
+// causal mask (an item's tile count is cut to its batch's keys), and with it on the ragged kernels (round 3: a block behind its batch's cut
+// runs the tiles of the visible keys without a diagonal); under the causal mask Sq == Sk (units are heavy + light block pairs, with an odd
+// block count the middle block is a unit of its own).
 bool p4_eligible(const pfa_fa3_args* a) {
     const bool split = (a->flags & PFA_FLAG_SPLIT_P) != 0, out32 = a->dtype_out == PFA_DTYPE_FP32;
     if ((a->D != 128 && a->D != 64) || split != out32) return false;
     const int64_t osz = out32 ? 4 : 2;
-    if (a->mask || (a->seqlens_k && a->causal)) return false;      // (seqlens_k under the causal mask: the HIP kernels)
+    if (a->mask || (a->seqlens_k && a->causal && a->key_mask)) return false;      // (key mask AND seqlens_k under the causal mask: the HIP kernels)
     if (a->key_mask && (a->key_mask_stride_b != a->Sk || (int64_t)a->B * a->Sk > 0x7fffffffLL)) return false;   // its 32-bit running byte offset
     const int64_t NBq = ((int64_t)a->Sq + 255) / 256;
     if (a->Sq < 128 || a->Sk < 193) return false;      // at least half a Q block of rows; at least four key tiles, the first three of them whole

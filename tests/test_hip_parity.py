@@ -958,3 +958,32 @@ def test_fast_loop_fixup_on_spiked_keys(case):
     assert float(el.max()) <= 1e-4
     pn = p.square().sum(-1).sqrt().permute(0, 2, 1)[..., None].float()
     assert _fast_ok(out.float().cpu(), ref, pn, float(v.float().abs().max()), "bf16", tag=name)
+
+
+@pytest.mark.parametrize("case", [(6, 4, 1024, [1024, 0, 1, 300, 512, 769], 128), (4, 2, 2048, [2047, 1025, 256, 64], 128),
+                                  (3, 4, 1000, [1000, 999, 130], 128), (4, 4, 1024, [700, 1, 257, 1024], 64), (2, 8, 1280, [513, 1279], 128)])
+def test_p4_seqlens_under_the_causal_mask(case):
+    """Round 3: seqlens_k UNDER the causal mask (the padded decoder batch) on the persistent ragged kernels: a block that lies behind its
+    batch's cut runs only the 256-key groups that hold visible keys, without a diagonal; the block that holds the cut keeps its diagonal and
+    masks what lies past the length.  Cuts inside the first / a middle / the last group, on group and tile edges, lengths 0 and S, ragged S."""
+    from oracle import fa3_oracle as orc
+    from photonic_flash_attention_amd import _capi, ops, synth
+    B, H, S, lens, D = case
+    q, k, v = synth.qkv(B, H, S, S, D, 5200 + S, "bf16")
+    qd, kd, vd = (t.to("cuda:0").permute(0, 2, 1, 3) for t in (q, k, v))
+    o32, lse = ops.fa3_forward(qd, kd, vd, causal=True, seqlens_k=lens, out_dtype=torch.float32, return_lse=True)
+    o16, _ = ops.fa3_forward(qd, kd, vd, causal=True, seqlens_k=lens)
+    o44, l44 = ops.fa3_forward(qd, kd, vd, causal=True, seqlens_k=lens, out_dtype=torch.float32, return_lse=True, _variant=44)
+    torch.cuda.synchronize()
+    name = _capi.describe(ops.build_args(qd, kd, vd, o16, causal=True, seqlens_k=lens)[0])[0]
+    assert name == f"fa3_fwd_p4_bf16_d{D}_causal_kl_o16", name
+    ref = orc.attention_bshd(q, k, v, causal=True, seqlens_k=lens)
+    dead = torch.tensor(lens) == 0
+    ref[dead] = 0.0                                                             # the kernels' convention for rows without a visible key
+    err = float((o32.permute(0, 2, 1, 3).cpu() - ref).abs().max())
+    print(f"{case}: {name}: parity variant max-abs {err:.3e}")
+    assert err <= PARITY_TOL, (case, err)
+    assert float((o32 - o44).abs().max()) <= 3e-5
+    assert float((o16.float() - o32).abs().max()) <= 2e-2
+    inf = torch.isinf(lse)
+    assert bool((inf == dead.to("cuda:0").view(B, 1, 1).expand(B, H, S)).all()) and float((lse - l44)[~inf].abs().max()) <= 2e-5
