@@ -1,15 +1,22 @@
-// fa3_bwd_f32_kernel.h -- fp32 backward of the attention core, for the cases the MFMA backward does not take: fp32 operands and
-// attention dropout (the reference's dense branch, flash_attention_3.py:174-175; it differentiates through its eager core with
-// autograd, this is that gradient).  Companion of fa3_fwd_f32_kernel.h: every product and sum in fp32, plain register micro-tiles.
+// fa3_bwd_f32_kernel.h -- fp32 backward of the attention core on the matrix cores (v_mfma_f32_32x32x2_f32: fp32 operands, bitwise an
+// fmaf chain, at the fp32 vector rate), for the cases the 16-bit MFMA backward does not take: fp32 operands (fp32 modules, the reference's
+// default dtype) and attention dropout (the reference's dense branch, flash_attention_3.py:174-175; it differentiates through its eager
+// core with autograd, this is that gradient).  Companion of fa3_fwd_f32_kernel.h.  Round 2's version was a VALU micro-tiling.
 //
 //   S = scale Q K^T (+ masks),  P = exp(S - lse),  Pd = P o keep * drop_scale,  O = Pd V
 //   delta_i = sum_d dO_id O_id,  dPd = dO V^T,  dS = P o (dPd o keep * drop_scale - delta_i)
 //   dQ = scale dS K,   dK = scale dS^T Q,   dV = Pd^T dO
 //
-// One kernel, two roles (template MODE): MODE 0 owns 64 query rows and walks the keys 32 at a time (-> dQ); MODE 1 owns 64 keys and
-// walks the queries 32 at a time (-> dK, dV).  No atomics, bitwise reproducible.  The "own" operands (Q, dO / K, V) and the tile
-// of the other side sit transposed in LDS ([d][row]); thread (tid / 8, tid % 8) computes a 2 x 4 micro-tile of S and dP, the tiles of
-// dS (and Pd) go through LDS, thread (tid / 16, tid % 16) accumulates 4 rows x D / 16 columns of the gradients.
+// One kernel, two roles (template MODE), no atomics, bitwise reproducible.  A workgroup of 4 waves owns 128 rows of the OWN side
+// (MODE 0: queries -> dQ; MODE 1: keys -> dK, dV), a wave 32 of them, and walks the OTHER side 32 rows at a time through a
+// double-buffered padded LDS image of its two operands (MODE 0: K, V; MODE 1: Q, dO).  A lane keeps half of its own two rows in
+// registers (contraction index paired (d, d + D/2), as in the forward).  Per tile, with "own" on the MFMA lane (column) and the tile's
+// rows on the accumulator registers (row crow(e, h) = (e & 3) + 8 (e >> 2) + 4 h):
+//   x1 = Y1 . own1^T   (MODE 0: S^T = K Q^T;  MODE 1: S = Q K^T)         x2 = Y2 . own2^T   (MODE 0: dP^T = V dO^T;  MODE 1: dP = dO V^T)
+//   P, dS element-wise (lse / delta: the lane's own scalars in MODE 0, per register from LDS in MODE 1)
+//   acc1^T += Y1^T . dS  (MODE 0: dQ^T += K^T dS^T;  MODE 1: dK^T += Q^T dS)      MODE 1 only: acc2^T += Y2^T . Pd  (dV^T += dO^T Pd)
+// -- the SAME code for both roles: dS / Pd registers are the B operand as they stand, the A operand Y[crow(e, h)][32 db + (lane & 31)] is a
+// conflict-free ds_read_b32 of the row-major image.  192 (MODE 0) / 256 (MODE 1) MFMAs of depth 2 per 32 x 32 tile.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,24 +36,27 @@ struct F32BwdParams {
     float scale, drop_scale;
 };
 
-template <int D, int MODE>
-__global__ __launch_bounds__(256) void fa3_bwd_f32_kernel(const F32BwdParams p) {
-    constexpr int BM = 64, BN = 32, LO = BM + 4, LT = BN + 4, NC = D / 16;
-    extern __shared__ __attribute__((aligned(16))) float smem_b[];
-    float* X1 = smem_b;                  // own operand 1, transposed [D][LO]: Q (MODE 0) / K (MODE 1)
-    float* X2 = X1 + D * LO;             // own operand 2: dO / V
-    float* Y1 = X2 + D * LO;             // other side's tile, transposed [D][LT]: K / Q
-    float* Y2 = Y1 + D * LT;             //                                        V / dO
-    float* T1 = Y2 + D * LT;             // dS tile [BM][LT]
-    float* T2 = T1 + BM * LT;            // Pd tile [BM][LT] (MODE 1)
-    float* rowc = T2 + BM * LT;          // per other-side row: lse[BN], delta[BN] (MODE 1); own rows: delta[BM] (MODE 0)
+constexpr int F32B_BM = 128, F32B_BN = 32;
+template <int D> constexpr int f32_bwd_lds_bytes() { return (2 * 2 * F32B_BN * (D + 4) + 2 * 2 * F32B_BN) * 4; }      // 2 stages x (2 images + lse / delta rows)
 
-    const int tid = threadIdx.x;
+typedef float f32x16_b __attribute__((ext_vector_type(16)));
+
+template <int D, int MODE>
+__global__ __launch_bounds__(256, 1) void fa3_bwd_f32_kernel(const F32BwdParams p) {
+    constexpr int BM = F32B_BM, BN = F32B_BN, LD = D + 4, HD = D / 2, NDB = D / 32;
+    constexpr int TILE = BN * LD;
+    constexpr int NLD = BN * D / 4 / 256;
+    constexpr int STAGE = 2 * TILE + 2 * BN;               // floats per stage: Y1, Y2, lse[BN], delta[BN]
+    extern __shared__ __attribute__((aligned(16))) float smem_b[];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, hh = lane >> 5;
     const int n_own = MODE == 0 ? p.Sq : p.Sk, n_oth = MODE == 0 ? p.Sk : p.Sq;
     const int nblk = (n_own + BM - 1) / BM;
-    const int bh = blockIdx.x / nblk, blk = blockIdx.x - bh * nblk;
+    const int bh = blockIdx.x / nblk;
+    int blk = blockIdx.x - bh * nblk;
+    if (p.causal && MODE == 0) blk = nblk - 1 - blk;       // heaviest query blocks first (key blocks: the first ones are the heaviest already)
     const int b = bh / p.H, h = bh - b * p.H;
-    const int r0 = blk * BM;
+    const int r0 = blk * BM, rw = r0 + wave * 32, own = rw + r;
     int kv_len = p.Sk;
     if (p.seqlens_k) kv_len = min(kv_len, max(p.seqlens_k[b], 0));
     const float* qp = p.q + (int64_t)b * p.q_sb + (int64_t)h * p.q_sh;
@@ -61,147 +71,176 @@ __global__ __launch_bounds__(256) void fa3_bwd_f32_kernel(const F32BwdParams p) 
     const float* oth1 = MODE == 0 ? kp : qp;
     const float* oth2 = MODE == 0 ? vp : gp;
     const int64_t oth1_ss = MODE == 0 ? p.k_ss : p.q_ss, oth2_ss = MODE == 0 ? p.v_ss : p.do_ss;
+    const float c = p.scale * 1.4426950408889634f;         // exp(x) = exp2(x log2 e)
 
-    for (int i = tid; i < BM * (D / 4); i += 256) {
-        const int r = i / (D / 4), c4 = i - r * (D / 4);
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
-        if (r0 + r < n_own) {
-            x = *(const float4*)(own1 + (int64_t)(r0 + r) * own1_ss + 4 * c4);
-            y = *(const float4*)(own2 + (int64_t)(r0 + r) * own2_ss + 4 * c4);
-        }
-        X1[(4 * c4 + 0) * LO + r] = x.x; X1[(4 * c4 + 1) * LO + r] = x.y; X1[(4 * c4 + 2) * LO + r] = x.z; X1[(4 * c4 + 3) * LO + r] = x.w;
-        X2[(4 * c4 + 0) * LO + r] = y.x; X2[(4 * c4 + 1) * LO + r] = y.y; X2[(4 * c4 + 2) * LO + r] = y.z; X2[(4 * c4 + 3) * LO + r] = y.w;
-    }
-    if (MODE == 0) {                     // delta of the own query rows: 4 threads per row
-        const int r = tid >> 2, part = tid & 3;
+    // this lane's half (d in [hh D/2, hh D/2 + D/2)) of its two own rows, kept for the whole block
+    float f1[HD], f2[HD];
+    float my_lse = INFINITY, my_delta = 0.f;               // MODE 0: the lane's query
+    {
+        const bool ok = own < n_own;
+        const float* a1 = own1 + (int64_t)(ok ? own : 0) * own1_ss + hh * HD;
+        const float* a2 = own2 + (int64_t)(ok ? own : 0) * own2_ss + hh * HD;
+        const float* ao = op + (int64_t)(ok ? own : 0) * p.o_ss + hh * HD;
         float d = 0.f;
-        if (r0 + r < p.Sq)
-            for (int c = part; c < D; c += 4) d = __builtin_fmaf(gp[(int64_t)(r0 + r) * p.do_ss + c], op[(int64_t)(r0 + r) * p.o_ss + c], d);
-        d += __shfl_xor(d, 1, 4);
-        d += __shfl_xor(d, 2, 4);
-        if (part == 0) rowc[r] = d;
+#pragma unroll
+        for (int i = 0; i < HD / 4; ++i) {
+            const float4 x = ok ? *(const float4*)(a1 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 y = ok ? *(const float4*)(a2 + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            f1[4 * i] = x.x; f1[4 * i + 1] = x.y; f1[4 * i + 2] = x.z; f1[4 * i + 3] = x.w;
+            f2[4 * i] = y.x; f2[4 * i + 1] = y.y; f2[4 * i + 2] = y.z; f2[4 * i + 3] = y.w;
+            if (MODE == 0 && ok) {                         // delta of the own query: this lane's half of sum_d dO O
+                d = __builtin_fmaf(y.x, ao[4 * i], d); d = __builtin_fmaf(y.y, ao[4 * i + 1], d);
+                d = __builtin_fmaf(y.z, ao[4 * i + 2], d); d = __builtin_fmaf(y.w, ao[4 * i + 3], d);
+            }
+        }
+        if (MODE == 0) {
+            my_delta = d + __shfl_xor(d, 32);
+            my_lse = ok ? lsep[own] : INFINITY;
+        }
     }
-    const int ty = tid >> 3, tx = tid & 7;             // S / dP micro-tile: own rows 2 ty, 2 ty + 1; other rows 4 tx .. +3
-    const int ty2 = tid >> 4, tx2 = tid & 15;          // gradient tile: own rows 4 ty2 .. +3, columns tx2 + 16 c
-    float acc1[4][NC], acc2[4][NC];
+    f32x16_b acc1[NDB], acc2[MODE == 1 ? NDB : 1];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int db = 0; db < NDB; ++db)
 #pragma unroll
-        for (int c = 0; c < NC; ++c) acc1[i][c] = acc2[i][c] = 0.f;
+        for (int e = 0; e < 16; ++e) {
+            acc1[db][e] = 0.f;
+            if (MODE == 1) acc2[db][e] = 0.f;
+        }
 
     // range of the other side that can see / be seen by this block
     int t_begin = 0, t_end = n_oth;
     if (MODE == 0) {
         t_end = p.causal ? min(kv_len, r0 + BM) : kv_len;
     } else if (p.causal) {
-        t_begin = (r0 / BN) * BN;                      // queries before the block's first key see none of its keys
+        t_begin = (r0 / BN) * BN;                          // queries before the block's first key see none of its keys
     }
-    for (int t0 = t_begin; t0 < t_end; t0 += BN) {
-        __syncthreads();
-        for (int i = tid; i < BN * (D / 4); i += 256) {
-            const int r = i / (D / 4), c4 = i - r * (D / 4);
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
-            if (t0 + r < n_oth) {
-                x = *(const float4*)(oth1 + (int64_t)(t0 + r) * oth1_ss + 4 * c4);
-                y = *(const float4*)(oth2 + (int64_t)(t0 + r) * oth2_ss + 4 * c4);
-            }
-            Y1[(4 * c4 + 0) * LT + r] = x.x; Y1[(4 * c4 + 1) * LT + r] = x.y; Y1[(4 * c4 + 2) * LT + r] = x.z; Y1[(4 * c4 + 3) * LT + r] = x.w;
-            Y2[(4 * c4 + 0) * LT + r] = y.x; Y2[(4 * c4 + 1) * LT + r] = y.y; Y2[(4 * c4 + 2) * LT + r] = y.z; Y2[(4 * c4 + 3) * LT + r] = y.w;
+    const int nt = t_end > t_begin ? (t_end - t_begin + BN - 1) / BN : 0;
+
+    float4 y1r[NLD], y2r[NLD];
+    auto fetch_stash = [&](int t, int stage) {
+        const int t0 = t_begin + t * BN;
+        float* Y1 = smem_b + stage * STAGE;
+        float* Y2 = Y1 + TILE;
+        float* rowc = Y2 + TILE;
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + 256 * j, row = i / (D / 4), c4 = i - row * (D / 4);
+            const bool ok = t0 + row < n_oth;
+            y1r[j] = ok ? *(const float4*)(oth1 + (int64_t)(t0 + row) * oth1_ss + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            y2r[j] = ok ? *(const float4*)(oth2 + (int64_t)(t0 + row) * oth2_ss + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (MODE == 1) {                 // lse and delta of the 32 queries of this tile: 8 threads per query
-            const int r = tid >> 3, part = tid & 7;
+        if (MODE == 1) {                                   // lse and delta of the tile's 32 queries: 8 threads per query
+            const int row = tid >> 3, part = tid & 7;
             float d = 0.f;
-            if (t0 + r < p.Sq)
-                for (int c = part; c < D; c += 8) d = __builtin_fmaf(gp[(int64_t)(t0 + r) * p.do_ss + c], op[(int64_t)(t0 + r) * p.o_ss + c], d);
+            if (t0 + row < p.Sq)
+                for (int cc = part * 4; cc < D; cc += 32) {
+                    const float4 g = *(const float4*)(gp + (int64_t)(t0 + row) * p.do_ss + cc);
+                    const float* oo = op + (int64_t)(t0 + row) * p.o_ss + cc;
+                    d = __builtin_fmaf(g.x, oo[0], d); d = __builtin_fmaf(g.y, oo[1], d);
+                    d = __builtin_fmaf(g.z, oo[2], d); d = __builtin_fmaf(g.w, oo[3], d);
+                }
             d += __shfl_xor(d, 1, 8);
             d += __shfl_xor(d, 2, 8);
             d += __shfl_xor(d, 4, 8);
             if (part == 0) {
-                rowc[r] = t0 + r < p.Sq ? lsep[t0 + r] : INFINITY;
-                rowc[BN + r] = d;
-            }
-        }
-        __syncthreads();
-        float s[2][4], dp[2][4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) s[i][j] = dp[i][j] = 0.f;
-#pragma unroll 8
-        for (int d = 0; d < D; ++d) {
-            const float a0 = X1[d * LO + 2 * ty], a1 = X1[d * LO + 2 * ty + 1];
-            const float g0 = X2[d * LO + 2 * ty], g1 = X2[d * LO + 2 * ty + 1];
-            const float4 c = *(const float4*)(Y1 + d * LT + 4 * tx);
-            const float4 e = *(const float4*)(Y2 + d * LT + 4 * tx);
-            const float cv[4] = {c.x, c.y, c.z, c.w}, ev[4] = {e.x, e.y, e.z, e.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                s[0][j] = __builtin_fmaf(a0, cv[j], s[0][j]);
-                s[1][j] = __builtin_fmaf(a1, cv[j], s[1][j]);
-                dp[0][j] = __builtin_fmaf(g0, ev[j], dp[0][j]);
-                dp[1][j] = __builtin_fmaf(g1, ev[j], dp[1][j]);
+                rowc[row] = t0 + row < p.Sq ? lsep[t0 + row] : INFINITY;
+                rowc[BN + row] = d;
             }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + 256 * j, row = i / (D / 4), c4 = i - row * (D / 4);
+            *(float4*)(Y1 + row * LD + 4 * c4) = y1r[j];
+            *(float4*)(Y2 + row * LD + 4 * c4) = y2r[j];
+        }
+    };
+    if (nt > 0) fetch_stash(0, 0);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int t0 = t_begin + t * BN;
+        if (t + 1 < nt) fetch_stash(t + 1, (t + 1) & 1);   // the other stage was last read one iteration ago (barrier below)
+        const float* Y1 = smem_b + (t & 1) * STAGE;
+        const float* Y2 = Y1 + TILE;
+        const float* rowc = Y2 + TILE;
+        // wave-uniform: does this wave's strip meet the tile at all under the causal mask?
+        const bool live = !p.causal || (MODE == 0 ? t0 <= rw + 31 : t0 + BN - 1 >= rw);
+        if (live) {
+            f32x16_b x1, x2;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int own = r0 + 2 * ty + i, oth = t0 + 4 * tx + j;
+            for (int e = 0; e < 16; ++e) x1[e] = x2[e] = 0.f;
+            const float* y1row = Y1 + r * LD + hh * HD;
+            const float* y2row = Y2 + r * LD + hh * HD;
+#pragma unroll
+            for (int i = 0; i < HD / 4; ++i) {
+                const float4 a = *(const float4*)(y1row + 4 * i);
+                x1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, f1[4 * i], x1, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, f1[4 * i + 1], x1, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, f1[4 * i + 2], x1, 0, 0, 0);
+                x1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, f1[4 * i + 3], x1, 0, 0, 0);
+                if (i % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < HD / 4; ++i) {
+                const float4 a = *(const float4*)(y2row + 4 * i);
+                x2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, f2[4 * i], x2, 0, 0, 0);
+                x2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, f2[4 * i + 1], x2, 0, 0, 0);
+                x2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, f2[4 * i + 2], x2, 0, 0, 0);
+                x2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, f2[4 * i + 3], x2, 0, 0, 0);
+                if (i % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+            // ---- P and dS: element e is (own row `own`, other row t0 + crow(e, hh))
+            const bool easy = !p.mask && !p.drop_mask && !p.causal && t0 + BN <= (MODE == 0 ? kv_len : p.Sq) &&
+                              (MODE == 0 ? rw + 31 < p.Sq : rw + 31 < kv_len);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int oth = t0 + (e & 3) + 8 * (e >> 2) + 4 * hh;
                 const int qi = MODE == 0 ? own : oth, kj = MODE == 0 ? oth : own;
-                bool vis = qi < p.Sq && kj < kv_len && (!p.causal || kj <= qi);
-                if (vis && p.mask) vis = p.mask[(int64_t)b * p.m_sb + (int64_t)h * p.m_sh + (int64_t)qi * p.m_sq + (int64_t)kj * p.m_sk] != 0;
-                const float lse = vis ? (MODE == 0 ? lsep[qi] : rowc[4 * tx + j]) : INFINITY;
-                const float dl = MODE == 0 ? rowc[2 * ty + i] : rowc[BN + 4 * tx + j];
-                const float pr = (vis && lse != -INFINITY) ? __expf(s[i][j] * p.scale - lse) : 0.f;      // lse = -inf: a row the forward found fully masked
+                const float lse = MODE == 0 ? my_lse : rowc[(e & 3) + 8 * (e >> 2) + 4 * hh];
+                const float dl = MODE == 0 ? my_delta : rowc[BN + (e & 3) + 8 * (e >> 2) + 4 * hh];
+                bool vis = true;
                 float keep = 1.f;
-                if (p.drop_mask && vis) keep = p.drop_mask[(((int64_t)b * p.H + h) * p.Sq + qi) * p.Sk + kj] ? p.drop_scale : 0.f;
-                const float ds = pr * (dp[i][j] * keep - dl);
-                T1[(2 * ty + i) * LT + 4 * tx + j] = ds * p.scale;
-                if (MODE == 1) T2[(2 * ty + i) * LT + 4 * tx + j] = pr * keep;
+                if (!easy) {
+                    vis = qi < p.Sq && kj < kv_len && (!p.causal || kj <= qi);
+                    if (vis && p.mask) vis = p.mask[(int64_t)b * p.m_sb + (int64_t)h * p.m_sh + (int64_t)qi * p.m_sq + (int64_t)kj * p.m_sk] != 0;
+                    if (p.drop_mask && vis) keep = p.drop_mask[(((int64_t)b * p.H + h) * p.Sq + qi) * p.Sk + kj] ? p.drop_scale : 0.f;
+                }
+                // lse = -inf: a row the forward found fully masked; +inf: a row that does not exist
+                const float pr = (vis && lse != -INFINITY && lse != INFINITY) ? __builtin_amdgcn_exp2f(__builtin_fmaf(x1[e], c, -lse * 1.4426950408889634f)) : 0.f;
+                x1[e] = pr * (x2[e] * keep - dl) * p.scale;                 // dS (scaled)
+                x2[e] = pr * keep;                                          // Pd
             }
-        __syncthreads();
-        // gradients: own rows 4 ty2 .. +3, columns tx2 + 16 c:  acc1 += dS x (other operand 1),  acc2 += Pd x (other operand 2)
-#pragma unroll 4
-        for (int j = 0; j < BN; ++j) {
-            float a[4], w[4];
+            // ---- acc1^T += Y1^T dS;  MODE 1: acc2^T += Y2^T Pd
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = T1[(4 * ty2 + i) * LT + j];
-                if (MODE == 1) w[i] = T2[(4 * ty2 + i) * LT + j];
-            }
+            for (int db = 0; db < NDB; ++db) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const float y1 = Y1[(tx2 + 16 * c) * LT + j];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc1[i][c] = __builtin_fmaf(a[i], y1, acc1[i][c]);
-                if (MODE == 1) {
-                    const float y2 = Y2[(tx2 + 16 * c) * LT + j];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) acc2[i][c] = __builtin_fmaf(w[i], y2, acc2[i][c]);
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    acc1[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(Y1[row * LD + 32 * db + r], x1[e], acc1[db], 0, 0, 0);
+                    if (MODE == 1) acc2[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(Y2[row * LD + 32 * db + r], x2[e], acc2[db], 0, 0, 0);
                 }
             }
         }
+        __syncthreads();
     }
+
+    // ---- epilogue: lane (own row, hh) stores columns 32 db + 8 g + 4 hh + 0..3
+    if (own < n_own) {
+        float* d1 = MODE == 0 ? p.dq + (int64_t)b * p.dq_sb + (int64_t)h * p.dq_sh + (int64_t)own * p.dq_ss
+                              : p.dk + (int64_t)b * p.dk_sb + (int64_t)h * p.dk_sh + (int64_t)own * p.dk_ss;
+        float* d2 = p.dv + (int64_t)b * p.dv_sb + (int64_t)h * p.dv_sh + (int64_t)own * p.dv_ss;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = r0 + 4 * ty2 + i;
-        if (r >= n_own) continue;
-        if (MODE == 0) {
-            float* d = p.dq + (int64_t)b * p.dq_sb + (int64_t)h * p.dq_sh + (int64_t)r * p.dq_ss;
+        for (int db = 0; db < NDB; ++db)
 #pragma unroll
-            for (int c = 0; c < NC; ++c) d[tx2 + 16 * c] = acc1[i][c];
-        } else {
-            float* dk = p.dk + (int64_t)b * p.dk_sb + (int64_t)h * p.dk_sh + (int64_t)r * p.dk_ss;
-            float* dv = p.dv + (int64_t)b * p.dv_sb + (int64_t)h * p.dv_sh + (int64_t)r * p.dv_ss;
+            for (int g = 0; g < 4; ++g) {
+                const int col = 32 * db + 8 * g + 4 * hh;
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                dk[tx2 + 16 * c] = acc1[i][c];
-                dv[tx2 + 16 * c] = acc2[i][c];
+                for (int j = 0; j < 4; ++j) {
+                    d1[col + j] = acc1[db][4 * g + j];
+                    if (MODE == 1) d2[col + j] = acc2[db][4 * g + j];
+                }
             }
-        }
     }
 }
-
-template <int D> constexpr int f32_bwd_lds_bytes() { return (2 * D * 68 + 2 * D * 36 + 2 * 64 * 36 + 128) * 4; }
 
 }  // namespace pfa

@@ -128,9 +128,9 @@ int pfa_fa3_bwd(const pfa_fa3_bwd_args* a, void* stream) {
             (void)hipFuncSetAttribute(f1, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         }
         void* kargs[] = {&p};
-        e = hipLaunchKernel(f0, dim3((unsigned)(((a->Sq + 63) / 64) * a->B * a->H)), dim3(256), kargs, (size_t)lds, (hipStream_t)stream);
+        e = hipLaunchKernel(f0, dim3((unsigned)(((a->Sq + pfa::F32B_BM - 1) / pfa::F32B_BM) * a->B * a->H)), dim3(256), kargs, (size_t)lds, (hipStream_t)stream);
         if (e == hipSuccess)
-            e = hipLaunchKernel(f1, dim3((unsigned)(((a->Sk + 63) / 64) * a->B * a->H)), dim3(256), kargs, (size_t)lds, (hipStream_t)stream);
+            e = hipLaunchKernel(f1, dim3((unsigned)(((a->Sk + pfa::F32B_BM - 1) / pfa::F32B_BM) * a->B * a->H)), dim3(256), kargs, (size_t)lds, (hipStream_t)stream);
         if (prev != a->device_id) (void)hipSetDevice(prev);
         if (e != hipSuccess) { (void)hipGetLastError(); return PFA_ERR_LAUNCH; }
         return PFA_OK;

@@ -589,16 +589,18 @@ def test_p4_kernel_reads_fused_qkv_views_and_is_the_default_for_long_aligned_pro
     assert _capi.describe(ops.build_args(q2, k2, v2, out[:, :, :2000], causal=False)[0])[0] == "fa3_fwd_p4_bf16_d128_full_kl_o16"
     q3, k3, v3 = (t[:, :, :700] for t in (q, k, v))            # an odd number of Q blocks under the causal mask: the middle block is a unit of its own
     assert _capi.describe(ops.build_args(q3, k3, v3, out[:, :, :700], causal=True)[0])[0] == "fa3_fwd_p4_bf16_d128_causal_kl_o16"
-    # not eligible -> the HIP kernels: short key sequences, Sq != Sk under the causal mask, element masks, causal seqlens, fp32 store with one P
+    # not eligible -> the HIP kernels: short key sequences, Sq != Sk under the causal mask, element masks, fp32 store with one P
     assert "p4" not in _capi.describe(ops.build_args(q2, k2[:, :, :192], v2[:, :, :192], out[:, :, :2000], causal=False)[0])[0]
     assert "p4" not in _capi.describe(ops.build_args(q3, k2, v2, out[:, :, :700], causal=True)[0])[0]
     o32 = torch.empty(B, S, H, D, device="cuda:0", dtype=torch.float32).permute(0, 2, 1, 3)
     assert _capi.describe(ops.build_args(q, k, v, o32, causal=False, split_p=True)[0])[0] == "fa3_fwd_p4_bf16_d128_full_splitp_o32"
     assert "p4" not in _capi.describe(ops.build_args(q, k, v, o32, causal=False, split_p=False)[0])[0]      # fp32 store, one P: HIP kernel
     assert _capi.describe(ops.build_args(q, k, v, out, causal=False, seqlens_k=[S, S - 1])[0])[0] == "fa3_fwd_p4_bf16_d128_full_kl_o16"
-    assert "p4" not in _capi.describe(ops.build_args(q, k, v, out, causal=True, seqlens_k=[S, S - 1])[0])[0]
-    # D = 64 (softmax-bound: two waves per SIMD overlap better): only while every unit has a CU of its own -- C2 yes, 16 x 16 x 2048 no
-    for (b, h, s, want) in ((4, 12, 1024, True), (16, 16, 2048, False)):
+    assert _capi.describe(ops.build_args(q, k, v, out, causal=True, seqlens_k=[S, S - 1])[0])[0] == "fa3_fwd_p4_bf16_d128_causal_kl_o16"      # round 3
+    km_ = torch.ones(B, S, dtype=torch.bool, device="cuda:0")
+    assert "p4" not in _capi.describe(ops.build_args(q, k, v, out, causal=True, seqlens_k=[S, S - 1], key_mask=km_)[0])[0]      # key mask AND seqlens_k under the causal mask
+    # D = 64: since round 3 (fast loop + mid-phase barrier) every eligible problem, also with several units per CU
+    for (b, h, s, want) in ((4, 12, 1024, True), (16, 16, 2048, True)):
         t = torch.empty(b, s, h, 64, device="cuda:0", dtype=torch.bfloat16).permute(0, 2, 1, 3)
         nm = _capi.describe(ops.build_args(t, t, t, torch.empty_like(t), causal=False)[0])[0]
         assert nm.startswith("fa3_fwd_p4_bf16_d64_full") == want, (b, h, s, nm)
