@@ -226,7 +226,11 @@ class Gen:
         self.nd_n, self.nd = ka('dbg'), ka('dbg', hi=True)     # (ragged kernels: the `dbg` kernarg pair is theirs -- no stamps, no mask bytes)
         self.cl = klen and causal              # seqlens_k under the causal mask: an item's tile count is cut to its batch's keys (decode)
         # fast: the plain kernels of the fast variant -- every row sees a key in its item's tile 0 (so its maximum is finite from there on)
-        self.fast = bool(FASTMAX) and not split and not kmask and not klen
+        # (ragged kernels too: with a prefix of visible keys -- Sk, seqlens_k -- a row sees key 0 unless its batch has no key at all, and then
+        #  it sees none in any tile; start_fast clamps such a row's maximum to -1e30, its weights are exp2(-inf) = 0.  Key-mask kernels
+        #  stay on the defer-max bodies: a row may come alive in a later tile there.)
+        self.fast = bool(FASTMAX) and not split and not kmask
+        self.ret = S('grow') if DIET else "s[58:59]"          # fix-up subroutine's return address (s[58:59] is a mask word of the ragged kernels)
         self.mb = self.fast and bool(MB) and STAMP in (0, 3)      # (on the parity variant's SAFE bodies it buys nothing at D = 128 and costs 4 % at D = 64)
         assert not (kmask and STAMP), "the key-mask kernels keep their mask words where the stamps keep their clock (s[58:59], the dbg kernarg)"
         assert D in (64, 128)
@@ -647,8 +651,10 @@ class Gen:
             for k in range(3, 31, 2):
                 o.append(f"v_max3_f32 {mx}, {mx}, {r[k]}, {r[k + 1]}")
             o.append(f"v_max_f32 {mx}, {mx}, {r[31]}")
-            o += [f"v_mov_b32 {t0}, {mx}", "s_nop 1", f"v_permlane32_swap_b32 {mx}, {t0}", f"v_max_f32 {mx}, {mx}, {t0}",
-                  f"v_mul_f32 {vr(STV(X, 'mc'))}, {ka('scale_log2')}, {mx}"]
+            o += [f"v_mov_b32 {t0}, {mx}", "s_nop 1", f"v_permlane32_swap_b32 {mx}, {t0}", f"v_max_f32 {mx}, {mx}, {t0}"]
+            if self.klen:                      # a batch without any key: every score is -inf; keep m finite so that x = s c - m c stays -inf
+                o.append(f"v_max_f32 {mx}, {NEG_BIG}, {mx}")
+            o.append(f"v_mul_f32 {vr(STV(X, 'mc'))}, {ka('scale_log2')}, {mx}")
         else:
             o += self.lupd(X)
         o += self.exp_block(X, b, 0, vr(STV(X, 'ps0')))
@@ -679,10 +685,10 @@ class Gen:
             for kb, ps in ((0, vr(STV(X, 'ps0'))), (1, vr(PS1(X)))):
                 self.i(f"v_mov_b32 {ps}, 0")
                 self.emit(self.exp_block(X, b, kb, ps, scaled=True))
-        self.rescale()                             # O *= alpha, both strips; leaves grow = 0
+        self.rescale(clear=not DIET)               # O *= alpha, both strips (the diet loop keeps its return address in `grow`)
         for X in "AB":
             self.i(f"v_mov_b32 {vr(STV(X, 'al'))}, 1.0")
-        self.i("s_setpc_b64 s[58:59]")
+        self.i(f"s_setpc_b64 {self.ret}")
 
     def fix_check(self, b):
         """behind the phase that finished the tile of S buffer b: call fixup(b) if a lane asked for it"""
@@ -700,7 +706,7 @@ class Gen:
         self.lab(la)
         self.i(f"s_add_u32 {S('t2', 0)}, {S('t2', 0)}, .L{self.name}_fixup{b}-{la}")
         self.i(f"s_addc_u32 {S('t2', 1)}, {S('t2', 1)}, 0")
-        self.i(f"s_swappc_b64 s[58:59], {S('t2')}")
+        self.i(f"s_swappc_b64 {self.ret}, {S('t2')}")
         self.i(f"s_branch {lb}")
         self.out_of_line(False)
 
@@ -1091,7 +1097,7 @@ class Gen:
             self.i(f"v_cndmask_b32 {vr(SBUF(buf, 'A', 0, e))}, {ninf}, {vr(SBUF(buf, 'A', 0, e))}, vcc")
             self.i(f"v_cndmask_b32 {vr(SBUF(buf, 'B', 1, e))}, {ninf}, {vr(SBUF(buf, 'B', 1, e))}, vcc")
 
-    def rescale(self):
+    def rescale(self, clear=True):
         """O *= alpha (per row; 1 exactly where the row max stayed inside its headroom)."""
         self.i("s_nop 15")
         self.i("s_nop 15")                    # last PV MFMA -> v_accvgpr_read
@@ -1106,7 +1112,8 @@ class Gen:
                 for k, a in enumerate(regs):
                     self.i(f"v_accvgpr_write_b32 a{a}, {vr(V_E[k])}")
         self.i("s_nop 7")
-        self.i(f"s_mov_b64 {S('grow')}, 0")
+        if clear:
+            self.i(f"s_mov_b64 {S('grow')}, 0")
 
     # ---- item decode: unit counter / sub item -> bases, descriptors, tile count (SALU only) ----------------------------------------
     def decode(self):
