@@ -989,3 +989,82 @@ def test_p4_seqlens_under_the_causal_mask(case):
     assert float((o16.float() - o32).abs().max()) <= 2e-2
     inf = torch.isinf(lse)
     assert bool((inf == dead.to("cuda:0").view(B, 1, 1).expand(B, H, S)).all()) and float((lse - l44)[~inf].abs().max()) <= 2e-5
+
+
+@pytest.mark.parametrize("case", [("S65536 causal, one head", 1, 1, 65536, 65536, 128, True), ("S32768, two heads", 1, 2, 32768, 32768, 128, False),
+                                  ("2048 heads x 512 causal", 64, 32, 512, 512, 128, True), ("S65535 causal, D64", 1, 1, 65535, 65535, 64, True),
+                                  ("Sq 128 x Sk 100001", 1, 8, 128, 100001, 128, False), ("4096 heads x 256", 128, 32, 256, 256, 128, False)])
+def test_persistent_kernel_extreme_shapes(case):
+    """The persistent kernels at the ends of their range (through the default dispatch): very long sequences, one head, thousands of
+    heads, a ragged 65535, a key sequence of 100001 -- against the 8-wave HIP kernel (same formulas, other summation order)."""
+    from photonic_flash_attention_amd import _capi, ops
+    tag, B, H, Sq, Sk, D, causal = case
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(len(tag))
+    q = torch.randn(B, Sq, H, D, device=dev, generator=g).to(torch.bfloat16).permute(0, 2, 1, 3)
+    k, v = (torch.randn(B, Sk, H, D, device=dev, generator=g).to(torch.bfloat16).permute(0, 2, 1, 3) for _ in range(2))
+    o0, l0 = ops.fa3_forward(q, k, v, causal=causal, return_lse=True)
+    o1, l1 = ops.fa3_forward(q, k, v, causal=causal, return_lse=True, _variant=44)
+    torch.cuda.synchronize()
+    name = _capi.describe(ops.build_args(q, k, v, o0, causal=causal)[0])[0]
+    d, dl = float((o0.float() - o1.float()).abs().max()), float((l0 - l1).abs().nan_to_num(0.0).max())
+    print(f"{tag}: {name}  |dO| {d:.1e} |dLSE| {dl:.1e}")
+    assert "p4" in name and bool(torch.isfinite(o0.float()).all()) and d <= 2e-2 and dl <= 1e-4
+
+
+def test_persistent_kernel_graph_of_three_flavours_side_stream_and_threads():
+    """One HIP graph holding a plain causal, a key-masked (with the seqlens_k hint derived on the device) and a ragged causal launch of
+    the persistent kernels, captured on a side stream and replayed three times bit for bit; then four host threads on four streams."""
+    import threading
+    from photonic_flash_attention_amd import ops
+    dev = _dev()
+
+    def mk(B, H, S, seed):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        return tuple(torch.randn(B, S, H, 128, device=dev, generator=g).to(torch.bfloat16).permute(0, 2, 1, 3) for _ in range(3))
+    q, k, v = mk(4, 8, 1024, 3)
+    lens = torch.tensor([1024, 300, 77, 640], device=dev)
+    km = torch.arange(1024, device=dev)[None, :] < lens[:, None]
+    qr, kr, vr = mk(2, 8, 1000, 4)
+    ref = {"plain": ops.fa3_forward(q, k, v, causal=True)[0].clone(), "km": ops.fa3_forward(q, k, v, key_mask=km)[0].clone(),
+           "ragged": ops.fa3_forward(qr, kr, vr, causal=True)[0].clone()}
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        o = ops.fa3_forward(q, k, v, causal=True)[0]
+    s.synchronize()
+    assert torch.equal(o, ref["plain"])
+    outs = {n: torch.empty_like(t) for n, t in ref.items()}
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            ops.fa3_forward(q, k, v, causal=True, out=outs["plain"])
+            ops.fa3_forward(q, k, v, key_mask=km, out=outs["km"])
+            ops.fa3_forward(qr, kr, vr, causal=True, out=outs["ragged"])
+    for rep in range(3):
+        for t in outs.values():
+            t.fill_(float("nan"))
+        g.replay()
+        torch.cuda.synchronize()
+        for n in ref:
+            assert torch.equal(outs[n], ref[n]), ("graph replay", n, rep)
+    errs = []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream()
+            qq, kk, vv = mk(2, 8, 512 + 256 * i, 10 + i)
+            with torch.cuda.stream(st):
+                a = ops.fa3_forward(qq, kk, vv, causal=True)[0]
+                for _ in range(50):
+                    b = ops.fa3_forward(qq, kk, vv, causal=True)[0]
+                st.synchronize()
+                if not torch.equal(a, b):
+                    errs.append(i)
+        except Exception as e:      # noqa: BLE001
+            errs.append((i, repr(e)))
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
