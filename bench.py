@@ -399,6 +399,18 @@ def main():
             step5()
         w5, kk5 = timed(step5, args.steps, 3)
         m5 = statistics.median(kk5)
+        km3 = (torch.arange(s2, device=dev)[None, :] < sl3[:, None])
+
+        def step6():                            # the same padding as a [B, Sk] key mask (what a module's 2-D attention_mask becomes): ops derives the cut
+            ops.fa3_forward(q2v, k2v, v2v, causal=True, key_mask=km3, out=o2v)
+        for _ in range(100):
+            step6()
+        w6, kk6 = timed(step6, args.steps, 3)
+        m6 = statistics.median(kk6)
+        others["C3_key_mask"] = {"ms": round(m6, 4), "tflops": round(flops(b2, h2, s2, d2, True) / (m6 * 1e-3) / 1e12, 2), "frac": None,
+                                 "kernel": _capi.describe(ops.build_args(q2v, k2v, v2v, o2v, causal=True, key_mask=km3)[0])[0],
+                                 "shape": "C3 under the causal mask with a [B, Sk] key-padding mask of the same lengths (dense-equivalent flops; "
+                                          "includes the two small device ops that derive the cut from the mask)"}
         others["C3_seqlens"] = {"ms": round(m5, 4), "tflops": round(flops(b2, h2, s2, d2, True) / (m5 * 1e-3) / 1e12, 2), "frac": None,
                                 "kernel": _capi.describe(ops.build_args(q2v, k2v, v2v, o2v, causal=True, seqlens_k=sl3)[0])[0],
                                 "shape": f"C3 with seqlens_k = {lens3} under the causal mask (dense-equivalent flops: the padding is not computed)"}

@@ -90,7 +90,7 @@ for nm, n, al in [("wave", 1, 1), ("ksrd", 4, 4), ("vsrd", 4, 4), ("qsrd_n", 4, 
                   ("ksrd_n", 2, 2), ("vsrd_n", 2, 2), ("grow", 2, 2), ("t2", 2, 2),
                   ("koff", 1, 1), ("voff", 1, 1), ("ktile", 1, 1), ("vtile", 1, 1), ("krem", 1, 1), ("vrem", 1, 1),
                   ("qrem", 1, 1), ("wrem", 1, 1), ("irem", 1, 1), ("nt_n", 1, 1), ("qdst", 1, 1), ("qoff", 1, 1),
-                  ("t0", 1, 1), ("t1", 1, 1), ("t3", 1, 1), ("w4k", 1, 1), ("xcd", 1, 1), ("slot", 1, 1), ("L_n", 1, 1),
+                  ("t0", 1, 1), ("t1", 1, 1), ("t3", 1, 1), ("w4k", 1, 1), ("nd_n", 1, 1), ("nd", 1, 1), ("L_n", 1, 1),
                   ("n_u", 1, 1), ("n_sub", 1, 1), ("n_valid", 1, 1), ("n_qblk", 1, 1), ("n_b", 1, 1), ("n_hh", 1, 1), ("n_nt", 1, 1)]:
     S.new(nm, n, al)
 
@@ -223,8 +223,13 @@ class Gen:
         # and start an item at the keys its batch has (seqlens_k; Sk without it, and always under the causal mask)
         self.kleft, self.kleft0 = (S('L_n'), ka('Sk')) if causal else (S('n_sub'), S('L_n'))
         self.mwords = kmask or klen            # (causal ragged kernels: the words carry seqlens_k; without it they are all ones where a row can look)
-        self.nd_n, self.nd = ka('dbg'), ka('dbg', hi=True)     # (ragged kernels: the `dbg` kernarg pair is theirs -- no stamps, no mask bytes)
-        self.cl = klen and causal              # seqlens_k under the causal mask: an item's tile count is cut to its batch's keys (decode)
+        self.nd_n, self.nd = S('nd_n'), S('nd')
+        # ... `Lcut`: where decode leaves the next item's key count L -- ragged kernels: L_n (it feeds their length words); key-mask kernels:
+        # the nt_full kernarg slot (unused under the causal mask), which is their `kleft0`, the keys the mask-byte stream starts an item with
+        self.Lcut = S('L_n') if klen else ka('nt_full')
+        if kmask and causal:
+            self.kleft0 = ka('nt_full')
+        self.cl = (klen or kmask) and causal              # seqlens_k under the causal mask: an item's tile count is cut to its batch's keys (decode)
         # fast: the plain kernels of the fast variant -- every row sees a key in its item's tile 0 (so its maximum is finite from there on)
         # (ragged kernels too: with a prefix of visible keys -- Sk, seqlens_k -- a row sees key 0 unless its batch has no key at all, and then
         #  it sees none in any tile; start_fast clamps such a row's maximum to -1e30, its weights are exp2(-inf) = 0.  Key-mask kernels
@@ -1125,8 +1130,12 @@ class Gen:
         lv, ln = self.ul("valid"), self.ul("decoded")
         # u = slot + SL * i  (the units of this XCD's heads, head-major, dealt round-robin over its CUs: a head's units run on
         # consecutive CUs at the same time)
+        # (slot / xcd of this workgroup: xcd_mode ? (xcd = wg & 7, slot = wg >> 3) : (xcd = 0, slot = wg); the workgroup id stays in s2)
+        self.i(f"s_lshr_b32 {t0}, s2, 3")
+        self.i(f"s_cmp_eq_u32 {ka('xcd_mode')}, 0")
+        self.i(f"s_cselect_b32 {t0}, s2, {t0}")                           # slot
         self.i(f"s_mul_i32 {u}, {S('n_u')}, {ka('SL')}")
-        self.i(f"s_add_u32 {u}, {u}, {S('slot')}")
+        self.i(f"s_add_u32 {u}, {u}, {t0}")
         self.i(f"s_mul_i32 {t0}, {ka('hx')}, {ka('NU')}")                 # the units of this XCD's heads
         self.i(f"s_cmp_lt_u32 {u}, {t0}")
         self.i(f"s_cbranch_scc1 {lv}")
@@ -1153,7 +1162,8 @@ class Gen:
         self.i(f"s_mov_b32 {S('n_qblk')}, {t1}")
         # bh = xcd_mode ? xcd + 8 lh : lh
         self.i(f"s_lshl_b32 {t3}, {t0}, 3")
-        self.i(f"s_add_u32 {t3}, {t3}, {S('xcd')}")
+        self.i(f"s_and_b32 {th}, s2, 7")                               # xcd
+        self.i(f"s_add_u32 {t3}, {t3}, {th}")
         self.i(f"s_cmp_eq_u32 {ka('xcd_mode')}, 0")
         self.i(f"s_cselect_b32 {t0}, {t0}, {t3}")                      # bh
         # b = bh / H, hh = bh % H, hkv = hh / kv_group
@@ -1224,7 +1234,7 @@ class Gen:
             # tiles of those groups like a non-causal item -- every wave the same tiles, no diagonal (nd_n = NODIAG).  Nothing past the
             # group of the last visible key is fetched or computed.
             lno = self.ul("noseqlens")
-            self.i(f"s_mov_b32 {S('L_n')}, {ka('Sk')}")
+            self.i(f"s_mov_b32 {self.Lcut}, {ka('Sk')}")
             self.i(f"s_mov_b32 {self.nd_n}, 0")
             self.i(f"s_load_dwordx2 {S('t2')}, s[0:1], {4 * KA_SEQLENS}")
             self.i("s_waitcnt lgkmcnt(0)")
@@ -1234,8 +1244,8 @@ class Gen:
             self.i(f"s_load_dword {t0}, {S('t2')}, {t0}")
             self.i("s_waitcnt lgkmcnt(0)")
             self.i(f"s_max_i32 {t0}, {t0}, 0")
-            self.i(f"s_min_i32 {S('L_n')}, {t0}, {ka('Sk')}")
-            self.i(f"s_add_u32 {t0}, {S('L_n')}, 255")
+            self.i(f"s_min_i32 {self.Lcut}, {t0}, {ka('Sk')}")
+            self.i(f"s_add_u32 {t0}, {self.Lcut}, 255")
             self.i(f"s_lshr_b32 {t0}, {t0}, 8")
             self.i(f"s_max_u32 {t0}, {t0}, 1")                          # G
             self.i(f"s_add_u32 {t1}, {S('n_qblk')}, 1")
@@ -1817,11 +1827,6 @@ class Gen:
         self.i("s_waitcnt lgkmcnt(0)")
         # slot / xcd of this workgroup: xcd_mode ? (xcd = wg & 7, slot = wg >> 3) : (xcd = 0, slot = wg)
         self.stamp_init()
-        self.i(f"s_and_b32 {S('xcd')}, s2, 7")
-        self.i(f"s_lshr_b32 {S('slot')}, s2, 3")
-        self.i(f"s_cmp_eq_u32 {ka('xcd_mode')}, 0")
-        self.i(f"s_cselect_b32 {S('xcd')}, 0, {S('xcd')}")
-        self.i(f"s_cselect_b32 {S('slot')}, s2, {S('slot')}")
         self.i(f"s_lshl_b32 {S('ktile')}, {ka('k_ss')}, 6")
         self.i(f"s_lshl_b32 {S('vtile')}, {ka('v_ss')}, 6")
         self.i(f"s_lshl_b32 {S('w4k')}, {W}, {12 if self.D == 128 else 11}")         # the wave's quarter of a tile image

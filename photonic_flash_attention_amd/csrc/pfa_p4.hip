@@ -147,7 +147,7 @@ bool p4_eligible(const pfa_fa3_args* a) {
     const bool split = (a->flags & PFA_FLAG_SPLIT_P) != 0, out32 = a->dtype_out == PFA_DTYPE_FP32;
     if ((a->D != 128 && a->D != 64) || split != out32) return false;
     const int64_t osz = out32 ? 4 : 2;
-    if (a->mask || (a->seqlens_k && a->causal && a->key_mask)) return false;      // (key mask AND seqlens_k under the causal mask: the HIP kernels)
+    if (a->mask) return false;                                         // (element masks: the HIP kernels)
     if (a->key_mask && (a->key_mask_stride_b != a->Sk || (int64_t)a->B * a->Sk > 0x7fffffffLL)) return false;   // its 32-bit running byte offset
     const int64_t NBq = ((int64_t)a->Sq + 255) / 256;
     if (a->Sq < 128 || a->Sk < 193) return false;      // at least half a Q block of rows; at least four key tiles, the first three of them whole

@@ -187,8 +187,8 @@ def build_args(q, k, v, out, *, causal=False, seqlens_k=None, key_mask=None, sof
         # the position behind each row's LAST visible key -- two small device ops, no sync, nothing changes in the result (those keys are
         # masked anyway) -- and the persistent kernel cuts every item's tile count to it.  Only where that kernel takes the problem and
         # the launch is long enough to carry the two extra ops (>= ~0.15 ms of attention).
-        if (seqlens_k is None and not causal and q.dtype != torch.float32 and D in (64, 128) and Sq >= 128 and Sk >= 193
-                and 4.0 * B * H * Sq * Sk * D >= 1.5e11):
+        if (seqlens_k is None and (not causal or Sq == Sk) and q.dtype != torch.float32 and D in (64, 128) and Sq >= 128 and Sk >= 193
+                and 4.0 * B * H * Sq * Sk * D >= 1.5e11):       # (under the causal mask too since round 3: the padded decoder batch)
             sl = _mask_bound(km)
             a.seqlens_k = sl.data_ptr()
             keep.append(sl)

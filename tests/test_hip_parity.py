@@ -598,7 +598,7 @@ def test_p4_kernel_reads_fused_qkv_views_and_is_the_default_for_long_aligned_pro
     assert _capi.describe(ops.build_args(q, k, v, out, causal=False, seqlens_k=[S, S - 1])[0])[0] == "fa3_fwd_p4_bf16_d128_full_kl_o16"
     assert _capi.describe(ops.build_args(q, k, v, out, causal=True, seqlens_k=[S, S - 1])[0])[0] == "fa3_fwd_p4_bf16_d128_causal_kl_o16"      # round 3
     km_ = torch.ones(B, S, dtype=torch.bool, device="cuda:0")
-    assert "p4" not in _capi.describe(ops.build_args(q, k, v, out, causal=True, seqlens_k=[S, S - 1], key_mask=km_)[0])[0]      # key mask AND seqlens_k under the causal mask
+    assert _capi.describe(ops.build_args(q, k, v, out, causal=True, seqlens_k=[S, S - 1], key_mask=km_)[0])[0] == "fa3_fwd_p4_bf16_d128_causal_km_o16"
     # D = 64: since round 3 (fast loop + mid-phase barrier) every eligible problem, also with several units per CU
     for (b, h, s, want) in ((4, 12, 1024, True), (16, 16, 2048, True)):
         t = torch.empty(b, s, h, 64, device="cuda:0", dtype=torch.bfloat16).permute(0, 2, 1, 3)
@@ -964,22 +964,36 @@ def test_fast_loop_fixup_on_spiked_keys(case):
 
 @pytest.mark.parametrize("case", [(6, 4, 1024, [1024, 0, 1, 300, 512, 769], 128), (4, 2, 2048, [2047, 1025, 256, 64], 128),
                                   (3, 4, 1000, [1000, 999, 130], 128), (4, 4, 1024, [700, 1, 257, 1024], 64), (2, 8, 1280, [513, 1279], 128)])
-def test_p4_seqlens_under_the_causal_mask(case):
+@pytest.mark.parametrize("with_mask", [False, True])
+def test_p4_seqlens_under_the_causal_mask(case, with_mask):
     """Round 3: seqlens_k UNDER the causal mask (the padded decoder batch) on the persistent ragged kernels: a block that lies behind its
     batch's cut runs only the 256-key groups that hold visible keys, without a diagonal; the block that holds the cut keeps its diagonal and
     masks what lies past the length.  Cuts inside the first / a middle / the last group, on group and tile edges, lengths 0 and S, ragged S."""
     from oracle import fa3_oracle as orc
     from photonic_flash_attention_amd import _capi, ops, synth
     B, H, S, lens, D = case
+    if with_mask and S % 256:
+        pytest.skip("key-mask kernels take whole blocks")
     q, k, v = synth.qkv(B, H, S, S, D, 5200 + S, "bf16")
     qd, kd, vd = (t.to("cuda:0").permute(0, 2, 1, 3) for t in (q, k, v))
-    o32, lse = ops.fa3_forward(qd, kd, vd, causal=True, seqlens_k=lens, out_dtype=torch.float32, return_lse=True)
-    o16, _ = ops.fa3_forward(qd, kd, vd, causal=True, seqlens_k=lens)
-    o44, l44 = ops.fa3_forward(qd, kd, vd, causal=True, seqlens_k=lens, out_dtype=torch.float32, return_lse=True, _variant=44)
+    # with_mask: the same lengths plus holes, as a [B, Sk] key mask AND seqlens_k (what ops derives from a padding mask): *_km_* kernels
+    km = (torch.rand(B, S, generator=torch.Generator().manual_seed(6)) < 0.85) if with_mask else None
+    if with_mask:
+        km[:, 0] = True                                                        # (key 0 stays: every live row of a causal problem sees it)
+    kw = dict(causal=True, seqlens_k=lens, key_mask=km.to("cuda:0") if with_mask else None)
+    o32, lse = ops.fa3_forward(qd, kd, vd, out_dtype=torch.float32, return_lse=True, **kw)
+    o16, _ = ops.fa3_forward(qd, kd, vd, **kw)
+    o44, l44 = ops.fa3_forward(qd, kd, vd, out_dtype=torch.float32, return_lse=True, _variant=44, **kw)
     torch.cuda.synchronize()
-    name = _capi.describe(ops.build_args(qd, kd, vd, o16, causal=True, seqlens_k=lens)[0])[0]
-    assert name == f"fa3_fwd_p4_bf16_d{D}_causal_kl_o16", name
-    ref = orc.attention_bshd(q, k, v, causal=True, seqlens_k=lens)
+    name = _capi.describe(ops.build_args(qd, kd, vd, o16, **kw)[0])[0]
+    assert name == f"fa3_fwd_p4_bf16_d{D}_causal_{'km' if with_mask else 'kl'}_o16", name
+    if with_mask:
+        keep = (torch.arange(S)[None, :] < torch.tensor(lens)[:, None]) & km
+        mask4 = keep.view(B, 1, 1, S) & (torch.arange(S)[None, :] <= torch.arange(S)[:, None]).view(1, 1, S, S)
+        ref = orc.flash_attention_forward(q.float().permute(0, 2, 1, 3), k.float().permute(0, 2, 1, 3), v.float().permute(0, 2, 1, 3),
+                                          mask4).permute(0, 2, 1, 3)
+    else:
+        ref = orc.attention_bshd(q, k, v, causal=True, seqlens_k=lens)
     dead = torch.tensor(lens) == 0
     ref[dead] = 0.0                                                             # the kernels' convention for rows without a visible key
     err = float((o32.permute(0, 2, 1, 3).cpu() - ref).abs().max())
