@@ -288,6 +288,36 @@ def test_hugging_face_models_run_on_the_kernel():
     err2 = float((got2 - ref2).abs().max())
     print(f"GPT-2 (2 layers) vs its sdpa path: max-abs {err2:.3e}")
     assert err2 <= 5e-2
+    # padded decoder batches (round 3): the mask interface hands the kernels the 2-D padding mask + the causal flag instead of a
+    # [B,1,Sq,Sk] tensor -> the persistent key-mask kernels, tile counts cut to each batch's keys; right and left padding
+    from photonic_flash_attention_amd.integration.pytorch import hf
+    seen = []
+    orig = hf.ops.fa3_attention
+
+    def spy(q, k, v, **kw):
+        seen.append((kw.get("causal"), None if kw.get("key_mask") is None else tuple(kw["key_mask"].shape), kw.get("mask") is not None))
+        return orig(q, k, v, **kw)
+    hf.ops.fa3_attention = spy
+    try:
+        for side in ("right", "left"):
+            am2 = torch.ones(2, 300, dtype=torch.long, device=DEV)
+            if side == "right":
+                am2[1, 210:] = 0
+            else:
+                am2[1, :90] = 0
+            pos = (am2.cumsum(-1) - 1).clamp(min=0)
+            with torch.no_grad():
+                conv2.config._attn_implementation = "sdpa"
+                want = conv2(input_ids=ids2, attention_mask=am2, position_ids=pos).last_hidden_state
+                conv2.config._attn_implementation = "pfa_hip"
+                seen.clear()
+                got3 = conv2(input_ids=ids2, attention_mask=am2, position_ids=pos).last_hidden_state
+            err3 = float((got3 - want)[am2.bool()].abs().max())
+            print(f"GPT-2, {side}-padded batch vs its sdpa path (valid positions): max-abs {err3:.3e}; kernel calls {seen[:1]}")
+            assert err3 <= 5e-2 and bool(torch.isfinite(got3[am2.bool()]).all())
+            assert seen and all(c is True and km == (2, 300) and not m4 for c, km, m4 in seen)      # flag + 2-D mask, no 4-D tensor
+    finally:
+        hf.ops.fa3_attention = orig
 
 
 def test_hugging_face_llama_style_gqa_model():
