@@ -159,6 +159,7 @@ MB = int(knob("P4_MB", "1"))              # fast loop: the iteration's barrier s
                                           # next QK^T phase are requested right behind it -- their latency and the barrier skew run under the rest of PV(j)
 MBGAP = int(knob("P4_MBGAP", "0"))        # ... behind this MFMA gap of the PV phase (0: 27 of 32 at D = 128, 12 of 16 at D = 64 -- same box, gaps 16..27 / 8..13:
                                           # the late barrier is worth +0.4..1 % over gap 20 at D = 128; at D = 64 gap 13 loses 2 %)
+KMFAST = int(knob("P4_KMFAST", "1"))      # key-mask kernels on the fast loop too (fresh rows: see Gen.__init__)
 DIET = int(knob("P4_DIET", "1"))          # fast loop: block sums start with t0 + t1 (no zeroing), one compare + s_cbranch_vccnz per tile for both strips
 FASTMAX = int(knob("P4_FASTMAX", "1"))    # the tile loop without a row max (Gen.fast; see finish_fast): a tile's exponentials are taken against the running
                                           # maximum, its scaled scores stay in the S buffer, and a row sum past 2^14 sends the wave to a fix-up subroutine
@@ -232,9 +233,11 @@ class Gen:
         self.cl = (klen or kmask) and causal              # seqlens_k under the causal mask: an item's tile count is cut to its batch's keys (decode)
         # fast: the plain kernels of the fast variant -- every row sees a key in its item's tile 0 (so its maximum is finite from there on)
         # (ragged kernels too: with a prefix of visible keys -- Sk, seqlens_k -- a row sees key 0 unless its batch has no key at all, and then
-        #  it sees none in any tile; start_fast clamps such a row's maximum to -1e30, its weights are exp2(-inf) = 0.  Key-mask kernels
-        #  stay on the defer-max bodies: a row may come alive in a later tile there.)
-        self.fast = bool(FASTMAX) and not split and not kmask
+        #  it sees none in any tile; start_fast clamps such a row's maximum to -1e30, its weights are exp2(-inf) = 0.  Key-mask kernels: a
+        #  row may come alive in a later tile (left padding).  Such a FRESH row keeps m c = 0, so that x = s c holds the score itself, and a
+        #  negative limit in STV thr: the tile check then fires for it whatever its sums are (unless the tile's mask word is zero) and the
+        #  fix-up gives it its first maximum.)
+        self.fast = bool(FASTMAX) and not split and (not kmask or bool(KMFAST))
         self.ret = S('grow') if DIET else "s[58:59]"          # fix-up subroutine's return address (s[58:59] is a mask word of the ragged kernels)
         self.mb = self.fast and bool(MB) and STAMP in (0, 3)      # (on the parity variant's SAFE bodies it buys nothing at D = 128 and costs 4 % at D = 64)
         assert not (kmask and STAMP), "the key-mask kernels keep their mask words where the stamps keep their clock (s[58:59], the dbg kernarg)"
@@ -635,6 +638,11 @@ class Gen:
         if not DIET:
             return []
         tt = vr(V_T[0])
+        if self.kmask:                         # the limit is a row's own (negative while the row is fresh)
+            tb = vr(V_T[1])
+            return [f"v_max_f32 {tt}, {vr(STV('A', 'ps0'))}, {vr(PS1('A'))}", f"v_max_f32 {tb}, {vr(STV('B', 'ps0'))}, {vr(PS1('B'))}",
+                    f"v_cmp_nge_f32 {S('t2')}, {vr(STV('B', 'thr'))}, {tb}", f"v_cmp_nge_f32 vcc, {vr(STV('A', 'thr'))}, {tt}",
+                    f"s_or_b64 vcc, vcc, {S('t2')}"]
         return [f"v_max3_f32 {tt}, {vr(STV('A', 'ps0'))}, {vr(PS1('A'))}, {vr(STV('B', 'ps0'))}",
                 f"v_max_f32 {tt}, {tt}, {vr(PS1('B'))}",
                 f"v_cmp_nge_f32 vcc, {vr(STV('A', 'thr'))}, {tt}"]       # not (2^14 >= sum): too large, or not a number
@@ -659,6 +667,11 @@ class Gen:
             o += [f"v_mov_b32 {t0}, {mx}", "s_nop 1", f"v_permlane32_swap_b32 {mx}, {t0}", f"v_max_f32 {mx}, {mx}, {t0}"]
             if self.klen:                      # a batch without any key: every score is -inf; keep m finite so that x = s c - m c stays -inf
                 o.append(f"v_max_f32 {mx}, {NEG_BIG}, {mx}")
+            if self.kmask:                     # no visible key in tile 0: a fresh row -- m = 0 (x = s c keeps the score), limit -1 (the check always fires)
+                o += [f"v_cmp_lt_f32 vcc, {NEG_BIG}, {mx}",
+                      f"v_mov_b32 {t0}, 0x46800000",
+                      f"v_cndmask_b32 {mx}, 0, {mx}, vcc",
+                      f"v_cndmask_b32 {vr(STV(X, 'thr'))}, -1.0, {t0}, vcc"]
             o.append(f"v_mul_f32 {vr(STV(X, 'mc'))}, {ka('scale_log2')}, {mx}")
         else:
             o += self.lupd(X)
@@ -682,6 +695,17 @@ class Gen:
             self.i(f"v_cmp_lt_f32 vcc, 8.0, {mx}")
             self.i("s_nop 1")
             self.i(f"v_cndmask_b32 {sh}, 0, {mx}, vcc")
+            if self.kmask:                     # a fresh row (limit < 0) takes the maximum of its first visible keys, whatever it is, and is fresh no more
+                t1, lim = vr(V_T[1]), vr(STV(X, 'thr'))
+                self.i(f"v_mov_b32 {t0}, {NEG_BIG}")
+                self.i(f"v_cmp_lt_f32 vcc, {t0}, {mx}")                        # the tile shows this row a key
+                self.i(f"v_mov_b32 {t0}, 0x46800000")
+                self.i(f"v_cndmask_b32 {t1}, 0, {mx}, vcc")
+                self.i(f"v_cndmask_b32 {t0}, {lim}, {t0}, vcc")
+                self.i(f"v_cmp_gt_f32 vcc, 0, {lim}")                          # fresh
+                self.i("s_nop 1")
+                self.i(f"v_cndmask_b32 {sh}, {sh}, {t1}, vcc")
+                self.i(f"v_cndmask_b32 {lim}, {lim}, {t0}, vcc")
             self.i(f"v_add_f32 {vr(STV(X, 'mc'))}, {vr(STV(X, 'mc'))}, {sh}")
             self.i(f"v_exp_f32 {vr(STV(X, 'al'))}, -{sh}")
             for x in r:
@@ -706,6 +730,9 @@ class Gen:
         self.lab(lb)
         self.out_of_line(True)
         self.lab(lc)
+        if self.kmask:                         # a tile without a visible key changes nothing (fresh rows ask every tile)
+            self.i(f"s_cmp_eq_u64 {self.MK(b)}, 0")
+            self.i(f"s_cbranch_scc1 {lb}")
         la = self.ul("pc")
         self.i(f"s_getpc_b64 {S('t2')}")
         self.lab(la)
@@ -1033,7 +1060,9 @@ class Gen:
         mid = None
         if self.mb:                            # the iteration's bookkeeping, counted wait and barrier inside PV(j); K(j+2)'s first fragments behind it
             if lean:
-                inline = [f"s_add_u32 {S('koff')}, {S('koff')}, {S('ktile')}", f"s_add_u32 {S('voff')}, {S('voff')}, {S('vtile')}", "s_waitcnt vmcnt(0)"]
+                inline = [f"s_add_u32 {S('koff')}, {S('koff')}, {S('ktile')}", f"s_add_u32 {S('voff')}, {S('voff')}, {S('vtile')}"] + \
+                         ([f"s_add_u32 {ka('pad')}, {ka('pad')}, 64"] if self.kmask else []) + ["s_waitcnt vmcnt(0)"] + \
+                         ([self.mask_word(p)] if self.kmask else [])
             else:
                 inline = self.capture(lambda: self.stream_bottom(p, barrier=False))
             mid = dict(gap=MBGAP or (27 if self.D == 128 else 12), inline=inline, kreads=self.kprefetch(p))
@@ -1852,7 +1881,7 @@ class Gen:
             self.lane_constants_d128(L, T0, T1, T2, T3, W)
         else:
             self.lane_constants_d64(L, T0, T1, T2, T3, W)
-        if self.fast:
+        if self.fast and not self.kmask:       # (key-mask kernels: start_fast sets a row's limit with its item's tile 0)
             for X in "AB":
                 self.i(f"v_mov_b32 {vr(STV(X, 'thr'))}, 0x46800000")              # 2^14: the tile-sum limit of the fast loop (finish_fast)
         # -- first item: decode, fetch its Q block, K0, then V0 and K1

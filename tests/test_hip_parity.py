@@ -1082,3 +1082,46 @@ def test_persistent_kernel_graph_of_three_flavours_side_stream_and_threads():
     [t.start() for t in th]
     [t.join() for t in th]
     assert not errs, errs
+
+
+@pytest.mark.parametrize("case", [(3, 4, 1024, False, 128), (3, 4, 1024, True, 128), (2, 8, 2048, True, 64), (2, 4, 512, False, 64)])
+def test_p4_key_mask_fresh_rows_left_padding(case):
+    """Key-mask kernels on the fast loop: a row that sees no key in its item's tile 0 (left padding, a hole at the start) is FRESH -- it
+    keeps m = 0 and a negative limit, so the per-tile check fires for it and the fix-up subroutine gives it its first maximum at the
+    first tile that shows it a key, whatever that maximum is (scores scaled up and down here).  Left padding of 1, 64, 65, 200 ... keys,
+    holes in the middle, a batch with no key at all; against the oracle and the 8-wave kernel."""
+    from photonic_flash_attention_amd import _capi, ops, synth
+    B, H, S, causal, D = case
+    q, k, v = synth.qkv(B, H, S, S, D, 6100 + S + D, "bf16")
+    q = (q.float() * torch.tensor([1.0, 6.0, 0.05])[:B].view(B, 1, 1, 1)).to(torch.bfloat16)       # first maxima far above / below 0
+    km = torch.ones(B, S, dtype=torch.bool)
+    km[0, :200] = False                          # left padding past three tiles
+    km[0, 400:600] = False                       # and a hole (all-masked tiles in the middle)
+    km[1, :65] = False
+    if B > 2:
+        km[2, :] = False                         # a batch without any key
+        km[2, 700:705] = True if causal else False
+    qd, kd, vd = (t.to("cuda:0").permute(0, 2, 1, 3) for t in (q, k, v))
+    kmd = km.to("cuda:0")
+    o32, lse = ops.fa3_forward(qd, kd, vd, causal=causal, key_mask=kmd, out_dtype=torch.float32, return_lse=True, _variant=44)
+    o16, l16 = ops.fa3_forward(qd, kd, vd, causal=causal, key_mask=kmd, return_lse=True)
+    torch.cuda.synchronize()
+    name = _capi.describe(ops.build_args(qd, kd, vd, o16, causal=causal, key_mask=kmd)[0])[0]
+    assert name == f"fa3_fwd_p4_bf16_d{D}_{'causal' if causal else 'full'}_km_o16", name
+    keep = km.view(B, 1, 1, S).expand(B, 1, S, S)
+    if causal:
+        keep = keep & (torch.arange(S)[None, :] <= torch.arange(S)[:, None]).view(1, 1, S, S)
+    # (the reference's tiled branch poisons a row whose 512-key tile is fully masked, flash_attention_3.py:249 -- outside the parity domain;
+    #  the yardstick here is the dense fp64 softmax, rows without any visible key 0 / -inf by the kernels' convention)
+    sc = torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double()) * D ** -0.5
+    sc = sc.masked_fill(~keep, float("-inf"))
+    dead = ~keep.any(dim=-1).expand(B, H, S)
+    pr = torch.softmax(sc, dim=-1).nan_to_num(0.0)
+    ref = torch.einsum("bhqk,bkhd->bhqd", pr, v.double()).float()
+    err16 = (o16.float().cpu() - ref).abs()
+    print(f"{name}: fast variant max-abs vs oracle {float(err16.max()):.3e}; vs the 8-wave parity kernel {float((o16.float() - o32).abs().max()):.3e}; "
+          f"dead rows {int(dead.sum())}")
+    assert float((o32.cpu() - ref).abs().max()) <= PARITY_TOL                  # (the reference kernel itself)
+    assert float(err16.max()) <= 3e-2
+    inf = torch.isinf(l16.cpu())
+    assert bool((inf == dead).all()) and float((l16 - lse).cpu()[~inf].abs().max()) <= 1e-4
