@@ -159,6 +159,8 @@ MB = int(knob("P4_MB", "1"))              # fast loop: the iteration's barrier s
                                           # next QK^T phase are requested right behind it -- their latency and the barrier skew run under the rest of PV(j)
 MBGAP = int(knob("P4_MBGAP", "0"))        # ... behind this MFMA gap of the PV phase (0: 27 of 32 at D = 128, 12 of 16 at D = 64 -- same box, gaps 16..27 / 8..13:
                                           # the late barrier is worth +0.4..1 % over gap 20 at D = 128; at D = 64 gap 13 loses 2 %)
+PSTART = int(knob("P4_PSTART", "1"))      # parity variant: key block 0's P is packed by the START stream, in the second half of the PV phase (behind the MFMAs
+                                          # that still read the previous tile's dwords 0..7), not by the finish: the QK^T phase carried 330 instructions in 32 gaps
 KMFAST = int(knob("P4_KMFAST", "1"))      # key-mask kernels on the fast loop too (fresh rows: see Gen.__init__)
 DIET = int(knob("P4_DIET", "1"))          # fast loop: block sums start with t0 + t1 (no zeroing), one compare + s_cbranch_vccnz per tile for both strips
 FASTMAX = int(knob("P4_FASTMAX", "1"))    # the tile loop without a row max (Gen.fast; see finish_fast): a tile's exponentials are taken against the running
@@ -290,6 +292,8 @@ class Gen:
 
     def emit(self, lst):
         for x in lst:
+            if x.startswith("@"):              # a packer marker (pack()): nothing to emit
+                continue
             if x.endswith(":"):
                 self.lab(x[:-1])
             else:
@@ -465,16 +469,9 @@ class Gen:
         fma = lambda e: f"v_fma_f32 {c1(e)}, {c1(e)}, {ka('scale_log2')}, -{mc}"
 
         def pack(i, x0, x1):
-            """P dword i = the pair (x0, x1) in 16 bits; split P: also the pair of what the rounding left behind"""
-            r = [f"{self.cvt} {vr(PD(X, i))}, {x0}, {x1}"]
-            if self.split:
-                t0, t1, hi = vr(tmp[0]), vr(tmp[1]), vr(PD(X, i))
-                if self.dt == "bf16":
-                    r += [f"v_lshlrev_b32 {t0}, 16, {hi}", f"v_and_b32 {t1}, 0xffff0000, {hi}"]
-                else:
-                    r += [f"v_cvt_f32_f16 {t0}, {hi}", f"v_cvt_f32_f16_sdwa {t1}, {hi} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"]
-                r += [f"v_sub_f32 {t0}, {x0}, {t0}", f"v_sub_f32 {t1}, {x1}, {t1}", f"{self.cvt} {vr(PDL(X, i))}, {t0}, {t1}"]
-            return r
+            if self.split and PSTART and i < 8:      # (key block 0: packed by the start stream, see start_stream)
+                return []
+            return self.pack_p(X, i, x0, x1, tmp)
         pk = PKADD and not self.split
         if pk:                                   # sums two at a time: both halves of a register pair per instruction
             acc = vr(PSP(X), 2)
@@ -521,6 +518,18 @@ class Gen:
         o.append(f"v_add_f32 {l}, {l}, {vr(ps1)}")
         o.append(f"v_mov_b32 {vr(ps1)}, 0")
         return o
+
+    def pack_p(self, X, i, x0, x1, tmp):
+        """P dword i = the pair (x0, x1) in 16 bits; split P: also the pair of what the rounding left behind"""
+        r = [f"{self.cvt} {vr(PD(X, i))}, {x0}, {x1}"]
+        if self.split:
+            t0, t1, hi = vr(tmp[0]), vr(tmp[1]), vr(PD(X, i))
+            if self.dt == "bf16":
+                r += [f"v_lshlrev_b32 {t0}, 16, {hi}", f"v_and_b32 {t1}, 0xffff0000, {hi}"]
+            else:
+                r += [f"v_cvt_f32_f16 {t0}, {hi}", f"v_cvt_f32_f16_sdwa {t1}, {hi} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"]
+            r += [f"v_sub_f32 {t0}, {x0}, {t0}", f"v_sub_f32 {t1}, {x1}, {t1}", f"{self.cvt} {vr(PDL(X, i))}, {t0}, {t1}"]
+        return r
 
     # softmax START of strip X on buffer `buf`, step u = 0..15 (row max, defer-max update, exponentials of key block 0)
     def start_fill(self, X, buf, u, alt=False):
@@ -582,6 +591,13 @@ class Gen:
                 o.append(f"v_add_f32 {ps0}, {ps0}, {n0(e - 1)}")
         if alt:
             o.append(f"v_mov_b32 {vr(V_PS1)}, 0")         # (it stood in for the row max)
+        if self.split and PSTART:
+            # key block 0's P dwords (hi and lo), behind the PV MFMAs of k-steps 0 / 1 that still read the previous tile's (marker: pack())
+            tmp = (V_T[2], V_T[3]) if alt else (V_T[0], V_T[1])
+            o.append(f"@gap {4 * 2 * self.DB + 1}")
+            o.append("s_nop 0")                            # (the last v_exp above and its consumer below)
+            for k in range(8):
+                o += self.pack_p(X, k, n0(2 * k), n0(2 * k + 1), tmp)
         return o
 
     # ---- the fast loop (self.fast): no row maximum inside the tile loop ------------------------------------------------------------
@@ -983,7 +999,7 @@ class Gen:
     def price(ins):
         """vector-issue cycles of one instruction beside MFMAs (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost')"""
         op = ins.split()[0]
-        if op.endswith(":"):
+        if op.endswith(":") or op.startswith("@"):
             return 0
         if op.startswith(("v_exp", "v_log", "v_rcp")):
             return 8
@@ -1007,11 +1023,18 @@ class Gen:
         for g in range(ngaps):
             room = budget - fixed[g] + (over * (g + 1)) // ngaps - (over * g) // ngaps     # spread the unavoidable excess evenly
             take = []
-            while st and room - self.price(st[0]) >= -2:
+            while st:
+                if st[0].startswith("@gap"):   # marker: what follows must not be issued before MFMA gap N
+                    if g < int(st[0].split()[1]):
+                        break
+                    st.pop(0)
+                    continue
+                if room - self.price(st[0]) < -2:
+                    break
                 room -= self.price(st[0])
                 take.append(st.pop(0))
             out.append(take)
-        return out, st
+        return out, [x for x in st if not x.startswith("@")]
 
     def body_full(self, p, lean=False):
         """lean: an iteration the caller knows to be far from the item's ends (no diagonal tile, see the loop in kernel())"""
