@@ -37,12 +37,19 @@ for it in range(N):
     else:
         q = torch.randn(B, Sq, H, D, device=dev, generator=gen).to(tdt).permute(0, 2, 1, 3)
         k, v = (torch.randn(B, Sk, H // g, D, device=dev, generator=gen).to(tdt).permute(0, 2, 1, 3) for _ in range(2))
-    kind = rnd.choice(["none", "none", "pad", "rand", "row0"])
-    lens = [rnd.choice([0, 1, Sk, rnd.randint(0, Sk)]) for _ in range(B)] if (not causal and rnd.random() < 0.3) else None
+    kind = rnd.choice(["none", "none", "pad", "rand", "row0", "left"])
+    lens = [rnd.choice([0, 1, Sk, rnd.randint(0, Sk)]) for _ in range(B)] if rnd.random() < 0.3 else None      # (round 3: under the causal mask too)
+    if rnd.random() < 0.25:                                  # a few keys far out: the fast loop's fix-up subroutine (and its fresh rows) get work
+        kk = k.permute(0, 2, 1, 3)
+        for _ in range(rnd.randint(1, 4)):
+            kk[:, rnd.randrange(Sk)] *= rnd.choice([4.0, 8.0, 20.0])
     km = None
     if kind == "pad":
         plen = torch.randint(1, Sk + 1, (B,), generator=gen, device=dev)
         km = torch.arange(Sk, device=dev)[None, :] < plen[:, None]
+    elif kind == "left":
+        pl = torch.randint(0, Sk, (B,), generator=gen, device=dev)
+        km = torch.arange(Sk, device=dev)[None, :] >= pl[:, None]
     elif kind in ("rand", "row0"):
         km = torch.rand(B, Sk, generator=gen, device=dev) < 0.75
         if kind == "row0":
@@ -50,7 +57,7 @@ for it in range(N):
     kw = dict(causal=causal, key_mask=km, seqlens_k=lens, return_lse=True)
     p45, l45 = ops.fa3_forward(q, k, v, out_dtype=torch.float32, _variant=45, **kw)
     p44, l44 = ops.fa3_forward(q, k, v, out_dtype=torch.float32, _variant=44, **kw)
-    f45 = ops.fa3_forward(q, k, v, causal=causal, key_mask=km, seqlens_k=lens, _variant=45)[0]
+    f45, lf45 = ops.fa3_forward(q, k, v, causal=causal, key_mask=km, seqlens_k=lens, return_lse=True, _variant=45)
     torch.cuda.synchronize()
     tag = (it, D, B, H, g, Sq, Sk, causal, kind, lens, dtype)
     name = _capi.describe(ops.build_args(q, k, v, f45, causal=causal, key_mask=km, seqlens_k=lens, variant=45)[0])[0]
@@ -60,8 +67,19 @@ for it in range(N):
     dead = torch.isinf(l44)
     assert torch.equal(dead, torch.isinf(l45)), tag
     dl = float((l45 - l44)[~dead].abs().max()) if bool((~dead).any()) else 0.0
-    assert d <= 3e-5 and dl <= 3e-5, (tag, d, dl)
-    assert float((f45.float() - p45).abs().max()) <= (2.5e-2 if dtype == "bf16" else 4e-3), tag      # store rounding + the rounding of P
+    scale = max(1.0, float(p44.abs().max()) / 4)            # (spiked keys: outputs and their half ulps grow)
+    assert d <= 3e-5 * scale and dl <= 3e-5 * max(1.0, float(l44[~dead].abs().max()) / 16 if bool((~dead).any()) else 1.0), (tag, d, dl)
+    ef = (f45.float() - p45).abs()
+    if float(ef.max()) > (2.5e-2 if dtype == "bf16" else 4e-3) * scale:      # store rounding + the rounding of P
+        i = int(ef.argmax())
+        idx = torch.unravel_index(torch.tensor(i), ef.shape)
+        lfd = float((lf45 - l44)[~dead].abs().max()) if bool((~dead).any()) else 0.0
+        print(f"FAST-vs-PARITY {tag}: max err {float(ef.max()):.4e} at {[int(x) for x in idx]} value {float(p45.flatten()[i]):.4f}; out max {float(p44.abs().max()):.3f}; "
+              f"fast LSE vs 8-wave {lfd:.2e}; elements over 2e-2: {int((ef > 2e-2).sum())} of {ef.numel()}", flush=True)
+        assert lfd <= 1e-3 and float(ef.max()) <= 2.0 ** -8 * max(1.0, float(p44.abs().max())) + 1.5e-2, tag      # half an ulp of the largest binade + the rounding of P
+    assert torch.equal(torch.isinf(lf45), dead), tag         # the fast variant (fast loop: plain / ragged / key-mask kernels) agrees on the dead rows
+    dlf = float((lf45 - l44)[~dead].abs().max()) if bool((~dead).any()) else 0.0
+    assert dlf <= 1e-4 * max(1.0, float(l44[~dead].abs().max()) / 16 if bool((~dead).any()) else 1.0), (tag, "fast LSE", dlf)
     worst[0], worst[1] = max(worst[0], d), max(worst[1], dl)
     if it % 25 == 24:
         print(f"{it + 1} ok (worst so far: out {worst[0]:.2e}, lse {worst[1]:.2e})", flush=True)
