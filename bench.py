@@ -489,6 +489,19 @@ def main():
                 fp32[tag] = {"ms": round(m4, 4), "tflops": round(flops(b2, h2, s2, d2, c2) / (m4 * 1e-3) / 1e12, 3),
                              "frac_of_fp32_matrix_peak": round(flops(b2, h2, s2, d2, c2) / (m4 * 1e-3) / 1e12 / 157.3, 4),
                              "kernel": _capi.describe(a4)[0], "shape": f"B={b2} S={s2} H={h2} D={d2} fp32 non-causal"}
+                # its backward (fa3_bwd_f32_kernel: the same fp32 MFMA, dQ pass + dK/dV pass), 2.5 x forward convention
+                o4, lse4 = ops.fa3_forward(q2, k2, v2, causal=c2, return_lse=True)
+                g4 = torch.randn(b2, s2, h2, d2, device=dev, dtype=torch.float32).permute(0, 2, 1, 3)
+
+                def step4b():
+                    ops.fa3_backward(q2, k2, v2, o4, g4, lse4, causal=c2)
+                for _ in range(2):
+                    step4b()
+                _w4b, k4b = timed(step4b, max(2, n_it // 2), 3)
+                m4b = statistics.median(k4b)
+                fp32[tag]["backward_ms"] = round(m4b, 4)
+                fp32[tag]["backward_tflops"] = round(2.5 * flops(b2, h2, s2, d2, c2) / (m4b * 1e-3) / 1e12, 3)
+                del o4, lse4, g4
                 del q2, k2, v2, o2
         except Exception as exc:   # noqa: BLE001
             fp32 = {"error": f"{type(exc).__name__}: {exc}"[:300]}

@@ -331,3 +331,50 @@ def test_hf_attention_registration_and_mask_dialect():
     assert model.config._attn_implementation != hf.IMPLEMENTATION_NAME and report.converted_layers
     with torch.no_grad(), pytest.raises((ValueError, RuntimeError)):
         conv(input_ids=torch.tensor([[1, 2, 3, 4]]))
+
+
+def test_hf_mask_interface_hands_on_the_compact_form():
+    """pfa_attention_mask: a plain causal / bidirectional prefill keeps the caller's 2-D padding mask (the triangle is a flag of the
+    kernels); cached decoding, offsets and user mask functions get sdpa's 4-D mask."""
+    pytest.importorskip("transformers")
+    import torch
+    from transformers import masking_utils as mu
+    from photonic_flash_attention_amd.integration.pytorch import hf
+    am = torch.ones(2, 16, dtype=torch.bool)
+    am[1, 10:] = False
+    kw = dict(batch_size=2, q_length=16, kv_length=16)
+    for fn in (mu.causal_mask_function, mu.bidirectional_mask_function):
+        got = hf.pfa_attention_mask(mask_function=fn, attention_mask=am, **kw)
+        assert got.dim() == 2 and torch.equal(got, am)
+        assert hf.pfa_attention_mask(mask_function=fn, attention_mask=None, **kw) is None
+    dec = hf.pfa_attention_mask(batch_size=2, q_length=1, kv_length=16, mask_function=mu.causal_mask_function, attention_mask=am, q_offset=15)
+    assert dec is None or dec.dim() == 4                                       # a decode step: sdpa's form (here nothing, or [B,1,1,Sk])
+    win = mu.and_masks(mu.causal_mask_function, mu.sliding_window_causal_mask_function(4)) if hasattr(mu, "and_masks") else None
+    if win is not None:
+        m4 = hf.pfa_attention_mask(mask_function=win, attention_mask=am, **kw)
+        assert m4 is not None and m4.dim() == 4 and m4.shape[-2:] == (16, 16)
+
+
+def test_generator_takes_no_knobs_in_the_product_build_and_is_deterministic(tmp_path):
+    """csrc/gen_fa3_fwd_p4.py: a P4_* knob left in the environment stops the product build (they are honoured only with P4_DEV=1,
+    which tools/p4_variants.py sets); two runs give byte-identical assembly, 48 kernels."""
+    import subprocess
+    import sys
+    gen = os.path.join(REPO, "photonic_flash_attention_amd", "csrc", "gen_fa3_fwd_p4.py")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("P4_")}
+    a = subprocess.run([sys.executable, gen], env=env, capture_output=True, text=True, timeout=300)
+    b = subprocess.run([sys.executable, gen], env=env, capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0 and a.stdout == b.stdout and a.stdout.count(".amdhsa_kernel ") == 48
+    bad = subprocess.run([sys.executable, gen], env=dict(env, P4_STAMP="1"), capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "P4_DEV" in bad.stderr and not bad.stdout
+
+
+def test_bench_reads_the_traffic_figure_from_the_newest_profile():
+    """bench.py roofline.traffic: parsed from profiles/r*_<workload>_rocprof_summary.md (FETCH_SIZE x 2 + WRITE_SIZE, KiB), not pasted."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("pfa_bench", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    b, src = bench.pmc_traffic("C3")
+    assert b is not None and "r03_C3_rocprof_summary" in src and 2.5e8 < b < 5e8
+    assert bench.pmc_traffic("nope") == (None, "no profiles/r*_nope_rocprof_summary.md")
