@@ -1624,7 +1624,8 @@ class Gen:
                 self.i(f"s_lshl_b32 {S('t0')}, {ka('o_ss')}, 5")                   # strip B: 32 rows further
             for k in range(NI):
                 self.i(f"s_waitcnt lgkmcnt({NI - 1 - k})")
-                self.i(f"buffer_store_dwordx4 {vr(x[k], 4)}, {vr(gofs)}, {S('osrd')}, {S('t0')} offen")
+                if not (saved and "nostore" in ABL):      # (TIMING-ONLY ablation: the seam path's epilogue without its output stores)
+                    self.i(f"buffer_store_dwordx4 {vr(x[k], 4)}, {vr(gofs)}, {S('osrd')}, {S('t0')} offen")
                 if k < NI - 1:
                     self.i(f"s_add_u32 {S('t0')}, {S('t0')}, {S('t1')}")
         self.i(f"v_mov_b32 {vr(V_PS1)}, 0")
@@ -2065,8 +2066,10 @@ class Gen:
             self.stream_bottom(1)
             if self.mb:
                 self.emit(self.kprefetch(1))   # the next item's iteration 0 (parity 0) reads K_next(1) from slot 1
-            self.item_epilogue(saved=True)
-            self.zero_o()
+            if "noepi" not in ABL:             # (TIMING-ONLY ablations of the seam path, wrong results: what an item costs outside its tile loop)
+                self.item_epilogue(saved=True)
+            if "nozero" not in ABL:
+                self.zero_o()
             self.item_switch()
             self.i(f"s_branch {lloop}")
         assert not self.lstack and self.L is self.main
