@@ -506,6 +506,35 @@ def main():
         except Exception as exc:   # noqa: BLE001
             fp32 = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
+    weights_leg = None
+    if world == 1 and not args.no_others:
+        try:   # need_weights (flash_attention_3.py:171,180,257-258): the softmax matrix [B,H,Sq,Sk] written by a second pass -- HBM-write bound
+            import ctypes as C
+            weights_leg = {}
+            for tag, (b2, h2, s2, d2, c2) in (("B2_H16_S2048_D128", (2, 16, 2048, 128, False)), ("B4_H16_S4096_D128", (4, 16, 4096, 128, False)),
+                                              ("B4_H16_S4096_D128_causal", (4, 16, 4096, 128, True)), ("B16_H12_S2048_D64", (16, 12, 2048, 64, False))):
+                q2, k2, v2, o2 = make(b2, h2, s2, d2, 99)
+                lse2 = torch.empty((b2, h2, s2), dtype=torch.float32, device=dev)
+                a2, keep2 = ops.build_args(*(t.permute(0, 2, 1, 3) for t in (q2, k2, v2, o2)), causal=c2, lse=lse2)
+                st2 = torch.cuda.current_stream(dev).cuda_stream
+                _capi.check_status(_capi.load().pfa_fa3_fwd(C.byref(a2), C.c_void_p(st2)))
+                w2 = torch.empty((b2, h2, s2, s2), dtype=torch.bfloat16, device=dev)
+
+                def step7():
+                    _capi.check_status(_capi.load().pfa_fa3_weights(C.byref(a2), C.c_void_p(w2.data_ptr()), _capi.PFA_DTYPE_BF16,
+                                                                    w2.stride(0), w2.stride(1), w2.stride(2), C.c_void_p(st2)))
+                for _ in range(3):
+                    step7()
+                _w7, k7 = timed(step7, 10, 3)
+                m7 = statistics.median(k7)
+                weights_leg[tag] = {"ms": round(m7, 4), "output_MB": round(w2.numel() * 2 / 1e6, 1),
+                                    "write_TBps": round(w2.numel() * 2 / (m7 * 1e-3) / 1e12, 3)}
+                del q2, k2, v2, o2, w2, lse2, keep2
+            weights_leg["what"] = ("pfa_fa3_weights alone (the forward's LSE given): bf16 weights, every element written once; the box's plain fill "
+                                   "rate is ~6.8 TB/s (tools/write_rate.py)")
+        except Exception as exc:   # noqa: BLE001
+            weights_leg = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
     if rank == 0:
         name, nwg = _capi.describe(ops.build_args(qv, kv, vv, outv, causal=causal, variant=args.variant)[0])
         achieved = f_rank / (kern_ms * 1e-3) / 1e12
@@ -546,6 +575,8 @@ def main():
             line["module"] = module
         if fp32:
             line["fp32_operands"] = fp32
+        if weights_leg:
+            line["need_weights"] = weights_leg
         if not args.no_parity:
             e16, e32 = parity_check(q, k, v, causal, [(0, 0), (B - 1, H - 1)], args.variant)
             line["parity"] = {"benched_kernel_bf16_out_max_abs": round(e16, 6),

@@ -126,6 +126,17 @@ struct TileDma {
             lds_dma16_buf(rb, off_b, lds_b + (wave + NW * t) * 1024);
         }
     }
+    // ... of slab A alone (fa3_weights_kernel.h: K tiles)
+    __device__ __forceinline__ void issue1(int wave, int j, const char* base_a, int64_t stride_a, int64_t slab_a, uint32_t lds_a) const {
+        const uint32_t step_a = (uint32_t)(ROWS_PER_T * 2) * (uint32_t)stride_a;
+        const uint32_t sa0 = (uint32_t)j * (uint32_t)(BLOCK_N * 2) * (uint32_t)stride_a;
+        const uint32_t la = (uint32_t)slab_a;
+#pragma unroll
+        for (int t = 0; t < PPW; ++t) {
+            const uint32_t sa = sa0 + t * step_a;
+            lds_dma16_buf(uniform_srd(base_a + sa, la > sa ? la - sa : 0u), off_a, lds_a + (wave + NW * t) * 1024);
+        }
+    }
 };
 
 // compile-time loop: f(IC<0>{}), f(IC<1>{}), ... f(IC<N-1>{})
