@@ -2,7 +2,8 @@
  * pfa_hip.h -- C ABI of libpfa_hip.so: the MI355X (gfx950) Flash-Attention forward (and backward) that
  * replaces the body of the reference's electronic attention core.
  * ABI history: v1 forward; v2 general masks + weights; v3 backward; v4 grouped-query heads (kv_group); v5 fp32 operands (exact
- * fp32 kernels, forward and backward) and dense-branch attention dropout; v6 pfa_fa3_prepare, reserve_cus, pfa_probe_mfma.
+ * fp32 kernels, forward and backward) and dense-branch attention dropout; v6 pfa_fa3_prepare, reserve_cus, pfa_probe_mfma;
+ * v7 pfa_fa3_bwd_args.kv_group (grouped-query heads in the backward: dK / dV summed over the group in the kernel).
  *
  * Reference seam (danieleschmidt/Photonic-Flash-Attention, all paths under
  * src/photonic_flash_attention/):
@@ -44,7 +45,7 @@
 extern "C" {
 #endif
 
-#define PFA_ABI_VERSION 6
+#define PFA_ABI_VERSION 7
 
 typedef enum pfa_status {
     PFA_OK = 0,
@@ -117,8 +118,8 @@ typedef struct pfa_fa3_args {
 
     /* ABI v4: grouped-query attention (not in the reference; what Hugging Face decoder models hand over).  k and v hold
      * H / kv_group heads and query head h reads K/V head h / kv_group, so nothing has to be expanded in memory.
-     * 0 or 1 = one K/V head per query head.  H must be a multiple of kv_group.  Forward and weights only: the
-     * backward wants expanded K/V (autograd then sums dK/dV over the group). */
+     * 0 or 1 = one K/V head per query head.  H must be a multiple of kv_group.  (The backward takes the same field since ABI v7:
+     * pfa_fa3_bwd_args.kv_group.) */
     int32_t kv_group;
     /* ABI v6: CUs to leave free (0 = none).  The persistent forward holds one workgroup on every CU for the whole launch, so a
      * kernel-based collective (RCCL) enqueued beside it only runs when it drains; a caller that overlaps such a collective passes
@@ -221,7 +222,8 @@ typedef struct pfa_fa3_bwd_args {
      * kernels; only they take the forward's dropout keep-mask (see pfa_fa3_args.drop_mask). */
     const uint8_t* drop_mask;
     float   drop_scale;
-    int32_t reserved1;          /* must be 0 */
+    int32_t kv_group;           /* ABI v7 (was reserved1, must-be-0): grouped-query heads as in pfa_fa3_args.kv_group -- k, v, dk, dv hold
+                                 * H / kv_group heads; dK / dV are summed over each group inside the kernel.  0 or 1 = none.  16-bit operands only. */
 } pfa_fa3_bwd_args;
 
 size_t pfa_fa3_bwd_workspace_bytes(const pfa_fa3_bwd_args* a);

@@ -13,7 +13,7 @@ import os
 import threading
 from typing import Optional
 
-PFA_ABI_VERSION = 6
+PFA_ABI_VERSION = 7
 PFA_DTYPE_BF16, PFA_DTYPE_FP16, PFA_DTYPE_FP32 = 0, 1, 2
 PFA_FLAG_SPLIT_P = 0x1
 PFA_FLAG_NO_XCD_MAP = 0x2
@@ -60,7 +60,7 @@ class PfaFa3BwdArgs(C.Structure):
         + [(n, C.c_int32) for n in ("B", "H", "Sq", "Sk", "D", "dtype", "dtype_grad", "causal")]
         + [("softmax_scale", C.c_float), ("device_id", C.c_int32)]
         + [("mask", C.c_void_p)] + [(f"mask_stride_{a}", C.c_int64) for a in "bhqk"]
-        + [("drop_mask", C.c_void_p), ("drop_scale", C.c_float), ("reserved1", C.c_int32)]
+        + [("drop_mask", C.c_void_p), ("drop_scale", C.c_float), ("kv_group", C.c_int32)]
     )
 
 

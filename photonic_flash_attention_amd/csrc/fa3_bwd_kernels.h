@@ -41,6 +41,7 @@ struct BwdParams {
     int64_t dq_sb, dq_sh, dq_ss, dk_sb, dk_sh, dk_ss, dv_sb, dv_sh, dv_ss;
     int32_t B, H, Sq, Sk;
     int32_t nblk;          // Q blocks (dq) or key blocks (dkdv)
+    int32_t kv_group;      // >= 1: query heads per K/V head (k, v, dk, dv hold H / kv_group heads; query head h uses K/V head h / kv_group)
     // a mask that depends on the key only ([B,Sk]: strides over heads and rows are 0) needs no KMASK kernels: the dK/dV kernel folds it
     // into its per-lane "this key exists" flag, the dQ kernel reads it four keys per load
     int32_t mask_dw;            // element mask rows are 4-byte aligned and Sk % 4 == 0: the dQ kernel reads them four keys per load
@@ -270,8 +271,9 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
 
     const T* qp = (const T*)p.q + (int64_t)b * p.q_sb + (int64_t)hh * p.q_sh;
     const T* gp = (const T*)p.dout + (int64_t)b * p.do_sb + (int64_t)hh * p.do_sh;
-    const char* kp = (const char*)((const T*)p.k + (int64_t)b * p.k_sb + (int64_t)hh * p.k_sh);
-    const char* vp = (const char*)((const T*)p.v + (int64_t)b * p.v_sb + (int64_t)hh * p.v_sh);
+    const int hk = hh / p.kv_group;          // grouped-query heads: the K/V head this query head reads
+    const char* kp = (const char*)((const T*)p.k + (int64_t)b * p.k_sb + (int64_t)hk * p.k_sh);
+    const char* vp = (const char*)((const T*)p.v + (int64_t)b * p.v_sb + (int64_t)hk * p.v_sh);
     const int64_t k_slab = ((int64_t)(p.Sk - 1) * p.k_ss + D) * 2, v_slab = ((int64_t)(p.Sk - 1) * p.v_ss + D) * 2;
 
     const int qrow = min(my_q, p.Sq - 1);
@@ -458,9 +460,12 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
 
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int BH = p.B * p.H, n = blockIdx.x, krank = n / BH, bh = n - krank * BH;
+    // grouped-query heads: a workgroup owns a key block of ONE K/V head and streams the Q / dO tiles of all its G query heads, one head
+    // after the other, into the same dK / dV accumulators (the sum over the group happens in registers, nothing is expanded in memory)
+    const int G = p.kv_group, HK = p.H / G;
+    const int BH = p.B * HK, n = blockIdx.x, krank = n / BH, bh = n - krank * BH;
     const int kblk = krank;                      // causal: low key blocks see the most query rows -> first
-    const int b = bh / p.H, hh = bh - b * p.H;
+    const int b = bh / HK, hh = bh - b * HK;     // hh: the K/V head
     const int k0 = kblk * BLOCK_K, wave_k0 = k0 + wave * 32, my_key = wave_k0 + r;
 
     int kv_len = p.Sk;
@@ -471,26 +476,26 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
     const int t_first = CAUSAL ? (k0 / BLOCK_N) : 0;
     const int nt = (p.Sq + BLOCK_N - 1) / BLOCK_N;
 
-    const char* qp = (const char*)((const T*)p.q + (int64_t)b * p.q_sb + (int64_t)hh * p.q_sh);
-    const char* gp = (const char*)((const T*)p.dout + (int64_t)b * p.do_sb + (int64_t)hh * p.do_sh);
+    const char* qp0 = (const char*)((const T*)p.q + (int64_t)b * p.q_sb + (int64_t)hh * G * p.q_sh);       // query head hh * G + gq: + gq * q_sh
+    const char* gp0 = (const char*)((const T*)p.dout + (int64_t)b * p.do_sb + (int64_t)hh * G * p.do_sh);
     const T* kp = (const T*)p.k + (int64_t)b * p.k_sb + (int64_t)hh * p.k_sh;
     const T* vp = (const T*)p.v + (int64_t)b * p.v_sb + (int64_t)hh * p.v_sh;
     const int64_t q_slab = ((int64_t)(p.Sq - 1) * p.q_ss + D) * 2, g_slab = ((int64_t)(p.Sq - 1) * p.do_ss + D) * 2;
-    const float* lse_p = p.lse + ((int64_t)b * p.H + hh) * p.Sq;
-    const float* del_p = p.delta + ((int64_t)b * p.H + hh) * p.Sq;
+    const float* lse_p0 = p.lse + ((int64_t)b * p.H + hh * G) * p.Sq;        // + gq * Sq
+    const float* del_p0 = p.delta + ((int64_t)b * p.H + hh * G) * p.Sq;
     // per-row constants of a 64-row tile, staged through LDS beside the tile: st[buf][0][64] = -lse/scale (or -inf
     // for rows that do not exist / are fully masked), st[buf][1][64] = -delta.  Thread t < 64 moves row t.
     constexpr int STAT_BASE = 2 * BUF_BYTES;
     typedef __attribute__((address_space(3))) float lds_float;
     typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
     float st_l = 0.f, st_d = 0.f;
-    auto stat_load = [&](int j) {
+    auto stat_load = [&](int gq, int j) {
         if (tid < BLOCK_N) {
             const int qi = j * BLOCK_N + tid;
             const bool live = qi < p.Sq;
-            const float l = live ? lse_p[qi] : -INFINITY;
+            const float l = live ? lse_p0[(int64_t)gq * p.Sq + qi] : -INFINITY;
             st_l = (l > -INFINITY) ? -l / p.scale : -INFINITY;
-            st_d = live ? -del_p[qi] : 0.f;
+            st_d = live ? -del_p0[(int64_t)gq * p.Sq + qi] : 0.f;
         }
     };
     auto stat_store = [&](int buf) {
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
     };
 
     const int krow = min(my_key, p.Sk - 1);
-    const uint8_t* mcol = KMASK ? p.mask + (int64_t)b * p.m_sb + (int64_t)hh * p.m_sh + (int64_t)krow * p.m_sk : nullptr;
+    const uint8_t* mcol0 = KMASK ? p.mask + (int64_t)b * p.m_sb + (int64_t)hh * G * p.m_sh + (int64_t)krow * p.m_sk : nullptr;     // + gq * m_sh
     v8 kf[KS], vf[KS];                       // K^T / V^T B-operand fragments: lane (key r, h) holds X[key][16ks+8h..+7]
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -525,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
         }
 
     // one 32-row half of a 64-row Q/dO tile
-    auto half = [&](auto bufc, auto hc, int q_base) {
+    auto half = [&](auto bufc, auto hc, int q_base, int gq) {
         constexpr int BOFF = decltype(bufc)::value * BUF_BYTES;
         constexpr int HOFF = decltype(hc)::value * HALF_TILE;
         // accumulators start at the per-row constants: S - lse/scale , dP - delta  (rows = queries = registers)
@@ -547,6 +552,7 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
         // under them; read where they are used, each half paid a full memory round trip
         uint32_t mbyte[16];
         if constexpr (KMASK) {
+            const uint8_t* mcol = mcol0 + (int64_t)gq * p.m_sh;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int qi = min(q_base + (e & 3) + 8 * (e >> 2) + 4 * h, p.Sq - 1);
@@ -615,25 +621,35 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
             });
         });
     };
-    auto step = [&](auto bufc, int j) {
+    // the stream: query head gq = 0 .. G-1, tiles t_first .. nt-1 of each; (cur_g, cur_j) is the tile in the buffer being computed
+    int cur_g = 0, cur_j = t_first;
+    const int ntl = nt - t_first, total = ntl > 0 ? G * ntl : 0;
+    auto step = [&](auto bufc, bool more) {
         constexpr int BUF = decltype(bufc)::value;
-        if (j + 1 < nt) {
-            dma.issue(wave, j + 1, qp, p.q_ss, q_slab, smem_base + (BUF ^ 1) * BUF_BYTES, gp, p.do_ss, g_slab,
-                      smem_base + (BUF ^ 1) * BUF_BYTES + TILE_BYTES);
-            stat_load(j + 1);                    // lands under this tile's math, written to LDS before the barrier
+        int nxt_g = cur_g, nxt_j = cur_j + 1;
+        if (nxt_j == nt) {
+            nxt_j = t_first;
+            ++nxt_g;
         }
-        const int q_base = j * BLOCK_N;
+        if (more) {
+            dma.issue(wave, nxt_j, qp0 + (int64_t)nxt_g * p.q_sh * 2, p.q_ss, q_slab, smem_base + (BUF ^ 1) * BUF_BYTES,
+                      gp0 + (int64_t)nxt_g * p.do_sh * 2, p.do_ss, g_slab, smem_base + (BUF ^ 1) * BUF_BYTES + TILE_BYTES);
+            stat_load(nxt_g, nxt_j);             // lands under this tile's math, written to LDS before the barrier
+        }
+        const int q_base = cur_j * BLOCK_N;
         // causal: a 32-row half whose last row is above this wave's first key contributes nothing
-        if (!CAUSAL || q_base + 31 >= wave_k0) half(bufc, IC<0>{}, q_base);
-        if (q_base + 32 < p.Sq && (!CAUSAL || q_base + 63 >= wave_k0)) half(bufc, IC<1>{}, q_base + 32);
-        if (j + 1 < nt) stat_store(BUF ^ 1);
+        if (!CAUSAL || q_base + 31 >= wave_k0) half(bufc, IC<0>{}, q_base, cur_g);
+        if (q_base + 32 < p.Sq && (!CAUSAL || q_base + 63 >= wave_k0)) half(bufc, IC<1>{}, q_base + 32, cur_g);
+        if (more) stat_store(BUF ^ 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
+        cur_g = nxt_g;
+        cur_j = nxt_j;
     };
-    if (t_first < nt) {
-        dma.issue(wave, t_first, qp, p.q_ss, q_slab, smem_base, gp, p.do_ss, g_slab, smem_base + TILE_BYTES);
-        stat_load(t_first);
+    if (total > 0) {
+        dma.issue(wave, t_first, qp0, p.q_ss, q_slab, smem_base, gp0, p.do_ss, g_slab, smem_base + TILE_BYTES);
+        stat_load(0, t_first);
         stat_store(0);
     }
 #pragma unroll
@@ -643,9 +659,9 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (int j = t_first; j < nt; j += 2) {
-        step(IC<0>{}, j);
-        if (j + 1 < nt) step(IC<1>{}, j + 1);
+    for (int i = 0; i < total; i += 2) {
+        step(IC<0>{}, i + 1 < total);
+        if (i + 1 < total) step(IC<1>{}, i + 2 < total);
     }
     if (!key_ok) {                              // keys in [kv_len, Sk): gradients are exactly zero
 #pragma unroll

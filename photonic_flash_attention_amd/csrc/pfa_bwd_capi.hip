@@ -17,7 +17,8 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 int check_bwd(const pfa_fa3_bwd_args* a) {
     if (!a) return PFA_ERR_NULL;
     if (a->size != sizeof(pfa_fa3_bwd_args)) return PFA_ERR_STRUCT_SIZE;
-    if (a->flags || a->reserved1) return PFA_ERR_FLAGS;
+    if (a->flags) return PFA_ERR_FLAGS;
+    if (a->kv_group < 0 || (a->kv_group > 1 && (a->H % a->kv_group || a->dtype == PFA_DTYPE_FP32))) return PFA_ERR_FLAGS;   // (fp32 kernels: one K/V head per query head)
     if (a->dtype == PFA_DTYPE_FP32) {          // fp32 backward kernels (fa3_bwd_f32_kernel.h): fp32 everything, the only path with dropout
         if (!a->q || !a->k || !a->v || !a->o || !a->dout || !a->lse || !a->dq || !a->dk || !a->dv) return PFA_ERR_NULL;
         if (a->B <= 0 || a->H <= 0 || a->Sq <= 0 || a->Sk <= 0) return PFA_ERR_SHAPE;
@@ -148,6 +149,7 @@ int pfa_fa3_bwd(const pfa_fa3_bwd_args* a, void* stream) {
     p.dk_sb = a->dk_stride_b; p.dk_sh = a->dk_stride_h; p.dk_ss = a->dk_stride_s;
     p.dv_sb = a->dv_stride_b; p.dv_sh = a->dv_stride_h; p.dv_ss = a->dv_stride_s;
     p.B = a->B; p.H = a->H; p.Sq = a->Sq; p.Sk = a->Sk;
+    p.kv_group = a->kv_group > 1 ? a->kv_group : 1;
     // a mask of the keys only (the reference's 2-D [B,Sk] mask arrives as [B,1,1,Sk]) runs on the unmasked kernels: see BwdParams::keymask
     const bool key_only = a->mask && a->mask_stride_h == 0 && a->mask_stride_q == 0 && a->mask_stride_k == 1 && a->Sk % 4 == 0 &&
                           a->mask_stride_b % 4 == 0 && ((uintptr_t)a->mask & 3) == 0;
@@ -189,7 +191,7 @@ int pfa_fa3_bwd(const pfa_fa3_bwd_args* a, void* stream) {
         p.nblk = (a->Sk + 127) / 128;
         if (lds + 1024 > 64 * 1024)   // tile stages + the per-row constants exceed the default 64 KiB dynamic-LDS limit
             (void)hipFuncSetAttribute(kdkdv, hipFuncAttributeMaxDynamicSharedMemorySize, lds + 1024);
-        e = hipLaunchKernel(kdkdv, dim3((unsigned)(p.nblk * BH)), dim3(256), args, (size_t)lds + 1024, (hipStream_t)stream);
+        e = hipLaunchKernel(kdkdv, dim3((unsigned)(p.nblk * (BH / p.kv_group))), dim3(256), args, (size_t)lds + 1024, (hipStream_t)stream);   // a workgroup per key block and K/V head
     }
     if (prev != a->device_id) (void)hipSetDevice(prev);
     if (e != hipSuccess) {

@@ -62,14 +62,8 @@ def pfa_attention_forward(module, query, key, value, attention_mask, dropout: fl
         raise NotImplementedError(f"'{IMPLEMENTATION_NAME}' attention does not return attention weights; use 'eager'")
     if dropout and getattr(module, "training", False):
         raise NotImplementedError("attention dropout in training mode is not implemented on the HIP path")
-    needs_grad = torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)
-    if key.shape[1] != query.shape[1] and needs_grad:
-        # grouped-query attention under autograd: the backward kernels want one K/V head per query head, and autograd
-        # through the expansion sums dK/dV over each group.  Without gradients the forward reads the shared heads in place
-        # (pfa_fa3_args.kv_group).
-        groups = query.shape[1] // key.shape[1]
-        key = key.repeat_interleave(groups, dim=1)
-        value = value.repeat_interleave(groups, dim=1)
+    # (grouped-query attention: forward and backward read the shared K/V heads in place -- pfa_fa3_args.kv_group, and since ABI v7
+    #  pfa_fa3_bwd_args.kv_group: the dK/dV kernel sums over each group in registers; nothing is expanded)
     if query.shape[-1] > 128:
         raise NotImplementedError(f"head_dim {query.shape[-1]} has no kernel (<= 128)")
     q_len, k_len = query.shape[2], key.shape[2]

@@ -304,12 +304,20 @@ def fa3_backward(q, k, v, out, dout, lse, *, causal: bool = False, seqlens_k=Non
     """dQ, dK, dV of ``fa3_forward`` (``pfa_fa3_bwd``).  All operands ``[B,H,S,D]``-shaped (any strides, head dim
     contiguous), ``lse`` the forward's ``[B,H,Sq]`` fp32 LSE.  Returns gradients as ``[B,H,S,D]`` views of
     ``[B,S,H,D]`` buffers, in ``grad_dtype`` (input dtype by default, or fp32).  ``key_mask`` / ``mask``: the masks
-    the forward was called with (same conventions as ``fa3_forward``)."""
+    the forward was called with (same conventions as ``fa3_forward``).  Grouped-query heads: ``k`` / ``v`` may hold ``H / g`` heads as in
+    the forward; ``dk`` / ``dv`` then have ``H / g`` heads too (summed over each group inside the dK/dV kernel, ABI v7)."""
     B, H, Sq, D = q.shape
     Sk = k.shape[2]
-    if k.shape[1] != H or v.shape[1] != H:
-        raise ValueError("pfa_fa3_bwd wants one K/V head per query head: expand grouped K/V (repeat_interleave) before the "
-                         "forward when gradients are needed; autograd then sums dK/dV over each group")
+    Hkv = k.shape[1]
+    if v.shape[1] != Hkv or Hkv <= 0 or H % Hkv:
+        raise ValueError(f"k / v carry {k.shape[1]} / {v.shape[1]} heads: both must hold H / g heads for an integer g (H = {H})")
+    if Hkv != H and q.dtype == torch.float32:
+        # the exact-fp32 kernels take one K/V head per query head: expand, and sum dK / dV over each group here
+        g = H // Hkv
+        dq, dk, dv = fa3_backward(q, k.repeat_interleave(g, dim=1), v.repeat_interleave(g, dim=1), out, dout, lse, causal=causal,
+                                  seqlens_k=seqlens_k, key_mask=key_mask, mask=mask, softmax_scale=softmax_scale, grad_dtype=grad_dtype,
+                                  drop_mask=drop_mask, drop_scale=drop_scale)
+        return dq, dk.reshape(B, Hkv, g, Sk, D).sum(2), dv.reshape(B, Hkv, g, Sk, D).sum(2)
     Dp = _padded_head_dim(D)
     if Dp != D:   # as in fa3_forward: zero-padded head dim; the gradients' extra columns are exactly zero and dropped
         grads = fa3_backward(_pad_d(q, Dp), _pad_d(k, Dp), _pad_d(v, Dp), _pad_d(out, Dp), _pad_d(dout, Dp), lse,
@@ -321,8 +329,8 @@ def fa3_backward(q, k, v, out, dout, lse, *, causal: bool = False, seqlens_k=Non
     if dout.stride(3) != 1:
         dout = dout.contiguous()
     dq = torch.empty((B, Sq, H, D), dtype=gdt, device=q.device).permute(0, 2, 1, 3)
-    dk = torch.empty((B, Sk, H, D), dtype=gdt, device=q.device).permute(0, 2, 1, 3)
-    dv = torch.empty((B, Sk, H, D), dtype=gdt, device=q.device).permute(0, 2, 1, 3)
+    dk = torch.empty((B, Sk, Hkv, D), dtype=gdt, device=q.device).permute(0, 2, 1, 3)      # grouped-query heads: dK / dV summed over
+    dv = torch.empty((B, Sk, Hkv, D), dtype=gdt, device=q.device).permute(0, 2, 1, 3)      # each group inside the kernel (ABI v7)
     delta = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
     a = _capi.PfaFa3BwdArgs()
     a.size = C.sizeof(_capi.PfaFa3BwdArgs)
@@ -355,6 +363,7 @@ def fa3_backward(q, k, v, out, dout, lse, *, causal: bool = False, seqlens_k=Non
         a.drop_mask, a.drop_scale = _drop_mask_ptr(drop_mask, B, H, Sq, Sk, q), float(drop_scale)
         keep.append(drop_mask)
     a.B, a.H, a.Sq, a.Sk, a.D = B, H, Sq, Sk, D
+    a.kv_group = H // Hkv
     a.dtype, a.dtype_grad, a.causal = _DT[q.dtype], _DT[gdt], 1 if causal else 0
     a.softmax_scale = float(D ** -0.5 if softmax_scale is None else softmax_scale)
     a.device_id = q.device.index if q.device.index is not None else torch.cuda.current_device()

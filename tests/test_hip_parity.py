@@ -669,7 +669,7 @@ def test_speedup_over_the_eager_tiled_loop_on_this_gpu():
                                   (1, 6, 2, 512, 1024, 128, False), (4, 8, 2, 512, 1024, 128, True)])
 def test_grouped_query_heads_read_in_place(case):
     """ABI v4 `kv_group`: K/V with H / g heads, query head h reading K/V head h // g, must equal the run on K/V expanded with
-    repeat_interleave bit for bit (both forward kernels), also for the weights pass; the backward refuses grouped K/V."""
+    repeat_interleave bit for bit (both forward kernels), also for the weights pass; the backward (ABI v7) sums dK / dV over each group."""
     from photonic_flash_attention_amd import ops, synth
     B, H, Hkv, Sq, Sk, D, causal = case
     q = synth.qkv(B, H, Sq, Sq, D, 611, "bf16")[0].to("cuda:0").permute(0, 2, 1, 3)
@@ -684,8 +684,20 @@ def test_grouped_query_heads_read_in_place(case):
         w_g = ops.fa3_forward(q, k, v, causal=causal, return_weights=True)[2]
         w_e = ops.fa3_forward(q, ke, ve, causal=causal, return_weights=True)[2]
         assert torch.equal(w_g, w_e)
+    # backward (ABI v7): dQ bit for bit as on the expanded heads; dK / dV = the expanded run's gradients summed over each group (the kernel
+    # sums in fp32 registers, the reference sum below adds rounded 16-bit gradients: a few bf16 ulps of the sum)
+    g = H // Hkv
+    dout = synth.qkv(B, H, Sq, Sq, D, 613, "bf16")[0].to("cuda:0").permute(0, 2, 1, 3)
+    dq_g, dk_g, dv_g = ops.fa3_backward(q, k, v, o_g, dout, l_g, causal=causal, grad_dtype=torch.float32)
+    dq_e, dk_e, dv_e = ops.fa3_backward(q, ke, ve, o_g, dout, l_g, causal=causal, grad_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert dk_g.shape == (B, Hkv, Sk, D) and dv_g.shape == (B, Hkv, Sk, D)
+    assert torch.equal(dq_g, dq_e), case
+    for got, exp in ((dk_g, dk_e), (dv_g, dv_e)):
+        want = exp.reshape(B, Hkv, g, Sk, D).sum(2)
+        assert float((got - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max())), case     # fp32 sums in another order
     with pytest.raises(ValueError):
-        ops.fa3_backward(q, k, v, o_g, o_g, l_g, causal=causal)
+        ops.fa3_backward(q, k[:, :1].expand(-1, 5, -1, -1) if H % 5 else k[:, :1], v, o_g, dout, l_g, causal=causal)      # head counts that do not divide
 
 
 @pytest.mark.parametrize("D", [8, 32, 40, 80, 96, 120])
