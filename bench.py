@@ -372,7 +372,14 @@ def main():
         q2v, k2v, v2v, o2v = (t.permute(0, 2, 1, 3) for t in (q2, k2, v2, o2))
         lens = torch.randint(s2 // 2, s2 + 1, (b2,), generator=torch.Generator().manual_seed(79)).to(dev)
         kmask = (torch.arange(s2, device=dev)[None, :] < lens[:, None]).to(torch.uint8)
-        for tag, kw in (("S2048", {}), ("S2048_key_mask", {"key_mask": kmask})):
+        # (+ the same B x H x S at head dim 64, the head dim of every shape the reference's own harness runs: many units per CU)
+        for tag, kw in (("S2048", {}), ("S2048_key_mask", {"key_mask": kmask}), ("S2048_D64", {})):
+            if tag == "S2048_D64":
+                del q2, k2, v2, o2
+                d2 = 64
+                q2, k2, v2, o2 = make(b2, h2, s2, d2, 81)
+                q2v, k2v, v2v, o2v = (t.permute(0, 2, 1, 3) for t in (q2, k2, v2, o2))
+
             def step3():
                 ops.fa3_forward(q2v, k2v, v2v, causal=False, out=o2v, **kw)
             for _ in range(100):
