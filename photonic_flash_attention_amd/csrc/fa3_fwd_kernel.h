@@ -421,7 +421,6 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
     constexpr int PIECES = TILE_BYTES / 1024;            // 16 (D=128) or 8 (D=64)
     constexpr int NDW = (VAR & VAR_DMA4) ? NW / 2 : NW;  // waves that issue DMA
     constexpr int PPW = PIECES / NDW;                    // pieces per issuing wave
-    typedef __attribute__((address_space(1))) const char gchar;
     int dma_key[PPW];
     int dma_col;                                         // element offset of the source chunk in its key row
     {
@@ -770,7 +769,7 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
         st_r0 = __builtin_amdgcn_s_memrealtime();
         __builtin_amdgcn_s_waitcnt(0xC07F);
     }
-    unsigned long long st_qk = 0;
+
     auto step = [&](auto bufc, int j) {
         constexpr int BUF = decltype(bufc)::value;
         if constexpr ((VAR & VAR_GLDS) && (VAR & VAR_STAMP)) {

@@ -338,6 +338,45 @@ def test_hugging_face_llama_style_gqa_model():
     assert err <= 5e-2 and bool(torch.isfinite(got).all())
 
 
+def test_hugging_face_llama_style_gqa_model_trains_without_expanding_kv():
+    """Same decoder in bf16 under autograd: the HIP path hands the backward K/V with 2 heads for 4 query heads (ABI v7, summed over the
+    group inside the dK/dV kernel); parameter gradients against the model's own sdpa path."""
+    transformers = pytest.importorskip("transformers")
+    from photonic_flash_attention_amd import convert_to_photonic, ops
+    torch.manual_seed(2)
+    cfg = transformers.LlamaConfig(hidden_size=256, num_attention_heads=4, num_key_value_heads=2, num_hidden_layers=2,
+                                   intermediate_size=512, vocab_size=500, max_position_embeddings=1024)
+    import copy
+    model32 = transformers.LlamaModel(cfg).to(DEV).train()
+    model = copy.deepcopy(model32).to(torch.bfloat16)
+    ids = torch.randint(0, 500, (2, 320), device=DEV)
+
+    def grads(m):
+        m.zero_grad(set_to_none=True)
+        (m(input_ids=ids).last_hidden_state.float().square().mean() * 1024.0).backward()
+        return {n: p.grad.float().clone() for n, p in m.named_parameters() if ("k_proj" in n or "v_proj" in n or "q_proj" in n) and p.grad is not None}
+    ref32 = grads(model32)           # the fp32 model on its own sdpa path: the yardstick
+    ref16 = grads(model)             # the bf16 model on its own sdpa path: what bf16 costs
+    conv, _ = convert_to_photonic(model)
+    seen = []
+    orig = ops.fa3_backward
+
+    def spy(q, k, v, *a, **kw):
+        seen.append((q.shape[1], k.shape[1]))
+        return orig(q, k, v, *a, **kw)
+    ops.fa3_backward = spy
+    try:
+        got = grads(conv)
+    finally:
+        ops.fa3_backward = orig
+    assert seen and all(hq == 4 and hk == 2 for hq, hk in seen), seen          # K/V were NOT expanded for the backward
+    assert set(got) == set(ref32) and len(got) >= 6
+    for n in ref32:
+        nrm = float(ref32[n].norm())
+        e_sdpa, e_pfa = float((ref16[n] - ref32[n]).norm()) / nrm, float((got[n] - ref32[n]).norm()) / nrm
+        assert e_pfa <= 1.5 * e_sdpa + 0.02, (n, e_pfa, e_sdpa)
+
+
 def test_training_dropout_follows_the_reference_branch_rule():
     """The reference drops attention weights only in its dense branch (S <= 512, `:174-175`); its tiled branch has no
     dropout.  A dropout > 0 module therefore trains at S = 640 with no dropout applied (two passes agree bit for bit), as in the
