@@ -66,6 +66,12 @@ struct FwdParams {
     // mb_sh = mb_sq = 0).  null: the mask is read a byte per score.
     const unsigned long long* mbits;
     int64_t mb_sb, mb_sh, mb_sq;
+    // ... and, per 256 mask rows, the first and last tile holding ANY visible key (fa3_maskrange_kernel): pairs (lo, hi) at
+    // mrange + 2 * (b*mr_sb + h*mr_sh + (mr_q ? q / 256 : 0)).  A Q block runs only tiles lo .. hi: a structured mask (a band, a
+    // triangle, padding) skips what it hides -- no fetch, no barrier -- instead of masking it.  null: every tile runs.
+    const int* mrange = nullptr;
+    int64_t mr_sb = 0, mr_sh = 0;
+    int32_t mr_q = 0;
 };
 
 template <typename T> struct Elem;
@@ -307,6 +313,66 @@ __global__ __launch_bounds__(256) void fa3_maskbits_kernel(const uint8_t* m, int
     if (lane == 0) out[(int64_t)b * ob + (int64_t)hh * oh + (int64_t)q * oq + tile] = bits;
 }
 
+// The same for keys contiguous in memory (m_sk = 1, rows / bases / Sk multiples of 16 bytes): a lane reads 16 mask bytes at once, four
+// lanes make a word, a wave 16 words of one row -- the byte-per-lane form above runs at 0.4 TB/s of mask, a 16 MB [S,S] mask cost
+// 43 us in front of a 280 us forward.
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void fa3_maskbits16_kernel(const uint8_t* m, int64_t sb, int64_t sh, int64_t sq, int Hm, int Sk, int nt,
+                                                            unsigned long long* out, int64_t ob, int64_t oh, int64_t oq) {
+    const int lane = threadIdx.x & 63, grp = blockIdx.x * 4 + (threadIdx.x >> 6), q = blockIdx.y;     // grp: 16 tiles = 1024 keys
+    const int b = blockIdx.z / Hm, hh = blockIdx.z - b * Hm;
+    if (grp * 16 >= nt) return;
+    const int key0 = grp * 1024 + 16 * lane;
+    uint32_t bits = 0;
+    if (key0 < Sk) {
+        const u32x4 x = *(const u32x4*)(m + (int64_t)b * sb + (int64_t)hh * sh + (int64_t)q * sq + key0);
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bits |= (((x[w] >> (8 * i)) & 0xFFu) != 0 ? 1u : 0u) << (4 * w + i);
+    }
+    unsigned long long word = (unsigned long long)bits << (16 * (lane & 3));
+    word |= __shfl_xor(word, 1);
+    word |= __shfl_xor(word, 2);
+    const int tile = grp * 16 + (lane >> 2);
+    if ((lane & 3) == 0 && tile < nt) out[(int64_t)b * ob + (int64_t)hh * oh + (int64_t)q * oq + tile] = word;
+}
+
+// first / last tile with a visible key per 256 mask rows (see FwdParams::mrange): RANGE_PARTS workgroups per granule and mask (batch, head),
+// each leaves the pair of its share of the rows; the forward kernel takes the minimum / maximum of the parts
+constexpr int RANGE_PARTS = 16;
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void fa3_maskrange_kernel(const unsigned long long* words, int64_t ob, int64_t oh, int64_t oq, int Hm, int Qm,
+                                                           int nt, int* out, int ngran) {
+    const int g = blockIdx.x / RANGE_PARTS, part = blockIdx.x - g * RANGE_PARTS, b = blockIdx.y / Hm, hh = blockIdx.y - b * Hm;
+    const int r0 = min(Qm, g * 256 + part * (256 / RANGE_PARTS)), r1 = min(Qm, r0 + 256 / RANGE_PARTS);
+    const unsigned long long* w = words + (int64_t)b * ob + (int64_t)hh * oh;
+    int lo = nt, hi = -1;
+    for (int idx = threadIdx.x; idx < (r1 - r0) * nt; idx += 256) {
+        const int row = r0 + idx / nt, t = idx - (idx / nt) * nt;
+        if (w[(int64_t)row * oq + t] != 0ull) {
+            lo = min(lo, t);
+            hi = max(hi, t);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off));
+        hi = max(hi, __shfl_xor(hi, off));
+    }
+    __shared__ int slo[4], shi[4];
+    if ((threadIdx.x & 63) == 0) {
+        slo[threadIdx.x >> 6] = lo;
+        shi[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int* o = out + 2 * ((((int64_t)b * Hm + hh) * ngran + g) * RANGE_PARTS + part);
+        o[0] = min(min(slo[0], slo[1]), min(slo[2], slo[3]));
+        o[1] = max(max(shi[0], shi[1]), max(shi[2], shi[3]));
+    }
+}
+
 template <typename T, int D, bool CAUSAL, bool SPLITP, bool KMASK, int VAR, typename OT>
 __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_kernel(const FwdParams p) {
     constexpr int NW = (VAR & VAR_NW4) ? 4 : 8;
@@ -367,7 +433,24 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
     if (p.seqlens_k) kv_len = min(kv_len, max(p.seqlens_k[b], 0));
     const int kv_end = CAUSAL ? min(kv_len, q0 + BLOCK_M) : kv_len;          // keys the block needs
     const int wave_kv_end = CAUSAL ? min(kv_len, wave_q0 + WAVE_M) : kv_len; // keys this wave needs
-    const int nt = (kv_end + BLOCK_N - 1) / BLOCK_N;
+    int nt = (kv_end + BLOCK_N - 1) / BLOCK_N;
+    int j0 = 0;                              // first tile of the block (0 unless the mask's tile range says otherwise)
+    if constexpr (KMASK && !(VAR & (VAR_RING3 | VAR_STAGE2))) {
+        if (p.mrange) {
+            const int* rg = p.mrange + 2 * RANGE_PARTS * ((int64_t)b * p.mr_sb + (int64_t)hh * p.mr_sh + (p.mr_q ? (q0 >> 8) : 0));
+            int lo = rg[2 * (lane & (RANGE_PARTS - 1))], hi = rg[2 * (lane & (RANGE_PARTS - 1)) + 1];
+#pragma unroll
+            for (int off = RANGE_PARTS / 2; off >= 1; off >>= 1) {
+                lo = min(lo, __shfl_xor(lo, off));
+                hi = max(hi, __shfl_xor(hi, off));
+            }
+            lo = __builtin_amdgcn_readfirstlane(lo);
+            hi = __builtin_amdgcn_readfirstlane(hi);
+            nt = min(nt, hi + 1);                                    // nothing visible past tile hi (hi = -1: nothing at all -> zeros, LSE -inf)
+            j0 = min(lo, max(nt, 0)) & ~1;                           // (even: the two LDS buffers keep their parity)
+            nt = max(nt, 0);
+        }
+    }
 
     const T* __restrict__ qp = (const T*)p.q + (int64_t)b * p.q_sb + (int64_t)hh * p.q_sh;
     const T* __restrict__ kp = (const T*)p.k + (int64_t)b * p.k_sb + (int64_t)(hh / p.kv_group) * p.k_sh;
@@ -809,15 +892,15 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
         }
     };
 
-    fetch_bits(0);
-    if (nt > 0) {
+    fetch_bits(j0);
+    if (nt > j0) {
         if constexpr (VAR & VAR_GLDS) {
-            dma_tile(IC<0>{}, 0);
+            dma_tile(IC<0>{}, j0);
             if constexpr ((VAR & VAR_STAGE2) || (VAR & VAR_RING3)) {
                 if (nt > 1) dma_tile(IC<1>{}, 1);
             }
         } else {
-            load_tile(0);
+            load_tile(j0);
             store_tile(IC<0>{});
         }
     }
@@ -875,7 +958,7 @@ __global__ __launch_bounds__(((VAR & VAR_NW4) ? 4 : 8) * 64, 2) void fa3_fwd_ker
             if (js + 1 < ns) stage(IC<1>{}, js + 1);
         }
     } else {
-        for (int j = 0; j < nt; j += 2) {
+        for (int j = j0; j < nt; j += 2) {
             step(IC<0>{}, j);
             if (j + 1 < nt) step(IC<1>{}, j + 1);
         }

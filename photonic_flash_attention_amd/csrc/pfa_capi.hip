@@ -250,7 +250,9 @@ struct MaskBits {
     int64_t sb = 0, sh = 0, sq = 0, sk = 0;      // byte strides of the source mask
     int64_t ob = 0, oh = 0, oq = 0;              // word strides of the result (0 = broadcast)
     const uint8_t* src = nullptr;
-    size_t bytes() const { return src ? (size_t)Bm * Hm * Qm * nt * sizeof(unsigned long long) : 0; }
+    int ngran = 0;                               // 256-row granules of the mask (fa3_maskrange_kernel: first / last visible tile of each)
+    size_t word_bytes() const { return src ? (size_t)Bm * Hm * Qm * nt * sizeof(unsigned long long) : 0; }
+    size_t bytes() const { return src ? word_bytes() + (size_t)Bm * Hm * ngran * pfa::RANGE_PARTS * 2 * sizeof(int) : 0; }
 };
 static MaskBits mask_bits(const pfa_fa3_args* a) {
     MaskBits m;
@@ -266,6 +268,7 @@ static MaskBits mask_bits(const pfa_fa3_args* a) {
         return m;
     }
     if (m.Qm > 65535 || (int64_t)m.Bm * m.Hm > 65535) { m.src = nullptr; return m; }      // launch limits: the byte path serves these
+    m.ngran = (m.Qm + 255) / 256;
     m.oq = m.Qm > 1 ? m.nt : 0;
     m.oh = m.Hm > 1 ? (int64_t)m.Qm * m.nt : 0;
     m.ob = m.Bm > 1 ? (int64_t)m.Hm * m.Qm * m.nt : 0;
@@ -273,9 +276,19 @@ static MaskBits mask_bits(const pfa_fa3_args* a) {
 }
 
 static bool launch_mask_bits(const MaskBits& mb, const pfa_fa3_args* a, void* stream) {
-    hipLaunchKernelGGL(pfa::fa3_maskbits_kernel<0>, dim3((unsigned)((mb.nt + 3) / 4), (unsigned)mb.Qm, (unsigned)(mb.Bm * mb.Hm)), dim3(256), 0,
-                       (hipStream_t)stream, mb.src, mb.sb, mb.sh, mb.sq, mb.sk, mb.Hm, a->Sk, mb.nt, (unsigned long long*)a->workspace,
-                       mb.ob, mb.oh, mb.oq);
+    const bool wide = mb.sk == 1 && a->Sk % 16 == 0 && mb.sb % 16 == 0 && mb.sh % 16 == 0 && mb.sq % 16 == 0 && ((uintptr_t)mb.src & 15) == 0;
+    if (wide)       // keys contiguous and 16-byte aligned: 16 mask bytes per lane
+        hipLaunchKernelGGL(pfa::fa3_maskbits16_kernel<0>, dim3((unsigned)(((mb.nt + 15) / 16 + 3) / 4), (unsigned)mb.Qm, (unsigned)(mb.Bm * mb.Hm)),
+                           dim3(256), 0, (hipStream_t)stream, mb.src, mb.sb, mb.sh, mb.sq, mb.Hm, a->Sk, mb.nt, (unsigned long long*)a->workspace,
+                           mb.ob, mb.oh, mb.oq);
+    else
+        hipLaunchKernelGGL(pfa::fa3_maskbits_kernel<0>, dim3((unsigned)((mb.nt + 3) / 4), (unsigned)mb.Qm, (unsigned)(mb.Bm * mb.Hm)), dim3(256), 0,
+                           (hipStream_t)stream, mb.src, mb.sb, mb.sh, mb.sq, mb.sk, mb.Hm, a->Sk, mb.nt, (unsigned long long*)a->workspace,
+                           mb.ob, mb.oh, mb.oq);
+    if (hipGetLastError() != hipSuccess) return false;
+    hipLaunchKernelGGL(pfa::fa3_maskrange_kernel<0>, dim3((unsigned)(mb.ngran * pfa::RANGE_PARTS), (unsigned)(mb.Bm * mb.Hm)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned long long*)a->workspace, mb.ob, mb.oh, mb.oq, mb.Hm, mb.Qm, mb.nt,
+                       (int*)((char*)a->workspace + mb.word_bytes()), mb.ngran);
     return hipGetLastError() == hipSuccess;
 }
 
@@ -365,6 +378,12 @@ int pfa_fa3_fwd(const pfa_fa3_args* a, void* stream) {
     const bool use_mbits = mb.src && a->workspace && a->workspace_bytes >= mb.bytes();
     p.mbits = use_mbits ? (const unsigned long long*)a->workspace : nullptr;
     p.mb_sb = mb.ob; p.mb_sh = mb.oh; p.mb_sq = mb.oq;
+    if (use_mbits) {
+        p.mrange = (const int*)((const char*)a->workspace + mb.word_bytes());
+        p.mr_sb = mb.Bm > 1 ? (int64_t)mb.Hm * mb.ngran : 0;
+        p.mr_sh = mb.Hm > 1 ? mb.ngran : 0;
+        p.mr_q = mb.Qm > 1 ? 1 : 0;
+    }
     const Variant v = pick(a);
     if (v.p4) {
         int herr = 0;

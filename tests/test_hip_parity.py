@@ -1137,3 +1137,57 @@ def test_p4_key_mask_fresh_rows_left_padding(case):
     assert float(err16.max()) <= 3e-2
     inf = torch.isinf(l16.cpu())
     assert bool((inf == dead).all()) and float((l16 - lse).cpu()[~inf].abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("case", [("window", 2, 3, 1536, 1536, 128), ("tril", 1, 2, 1024, 1024, 64), ("documents", 2, 2, 1280, 1280, 128),
+                                  ("dead_block", 1, 2, 768, 1024, 128), ("left_padding_4d", 2, 2, 600, 900, 64), ("per_head", 1, 3, 512, 1024, 128)])
+def test_element_masks_skip_the_tiles_they_hide(case):
+    """Element masks on the HIP kernels: beside the 64-bit word per row and tile, the condensing pass leaves the first / last tile with
+    any visible key per 256 mask rows (FwdParams::mrange); a Q block runs only that range.  Structured masks -- a sliding window, the
+    triangle as a mask, block-diagonal documents, a Q block that sees nothing, left padding, a different band per head -- against the
+    dense fp64 softmax (rows without a visible key: 0 / LSE -inf), parity variant <= 1e-3."""
+    from photonic_flash_attention_amd import _capi, ops, synth
+    kind, B, H, Sq, Sk, D = case
+    q, k, v = synth.qkv(B, H, Sq, Sk, D, 7300 + Sq + D, "bf16")
+    iq, ik = torch.arange(Sq)[:, None], torch.arange(Sk)[None, :]
+    if kind == "window":
+        keep = ((iq - ik >= 0) & (iq - ik < 200)).view(1, 1, Sq, Sk)
+    elif kind == "tril":
+        keep = (ik <= iq).view(1, 1, Sq, Sk)
+    elif kind == "documents":                    # three documents of unequal length, per batch a different split
+        keep = torch.zeros(B, 1, Sq, Sk, dtype=torch.bool)
+        for b_, cuts in enumerate([(0, 300, 1000, 1280), (0, 64, 65, 1280)][:B]):
+            for a0, a1 in zip(cuts[:-1], cuts[1:]):
+                keep[b_, 0, a0:a1, a0:a1] = True
+    elif kind == "dead_block":                   # rows 256..511 see nothing at all; the others a band in the middle of the keys
+        keep = torch.zeros(1, 1, Sq, Sk, dtype=torch.bool)
+        keep[..., :256, 300:700] = True
+        keep[..., 512:, 650:1024] = True
+    elif kind == "left_padding_4d":
+        keep = torch.ones(B, 1, 1, Sk, dtype=torch.bool).expand(B, 1, Sq, Sk).clone()
+        keep[0, ..., :333] = False
+        keep[1, ..., :64] = False
+    else:                                        # per head another band
+        keep = torch.zeros(1, H, Sq, Sk, dtype=torch.bool)
+        for h_ in range(H):
+            keep[0, h_, :, 200 * h_:200 * h_ + 300] = True
+    qd, kd, vd = (t.to("cuda:0").permute(0, 2, 1, 3) for t in (q, k, v))
+    md = keep.to("cuda:0")
+    o32, lse = ops.fa3_forward(qd, kd, vd, mask=md, out_dtype=torch.float32, return_lse=True)
+    o16, l16 = ops.fa3_forward(qd, kd, vd, mask=md, return_lse=True)
+    torch.cuda.synchronize()
+    name = _capi.describe(ops.build_args(qd, kd, vd, o16, mask=md)[0])[0]
+    assert "kmask" in name, name                                    # the HIP kernels (element masks never reach the assembly kernel)
+    full = keep.expand(B, H, Sq, Sk)
+    sc = torch.einsum("bqhd,bkhd->bhqk", q.double(), k.double()) * D ** -0.5
+    sc = sc.masked_fill(~full, float("-inf"))
+    dead = ~full.any(dim=-1)
+    ref = torch.einsum("bhqk,bkhd->bhqd", torch.softmax(sc, dim=-1).nan_to_num(0.0), v.double()).float()
+    ref_lse = torch.logsumexp(sc, dim=-1).float()
+    e32, e16 = float((o32.cpu() - ref).abs().max()), float((o16.float().cpu() - ref).abs().max())
+    print(f"{kind} {name}: parity variant {e32:.2e}, fast {e16:.2e}, rows without a key {int(dead.sum())}")
+    assert e32 <= PARITY_TOL and e16 <= 3e-2
+    for l_ in (lse.cpu(), l16.cpu()):
+        assert bool((torch.isinf(l_) == dead).all())
+        assert float((l_ - ref_lse)[~dead].abs().max()) <= 1e-4
+    assert bool((o16.float().cpu()[dead] == 0).all())
