@@ -153,9 +153,11 @@ int pfa_fa3_prepare(int device_id);
 int pfa_last_hip_error(void);
 
 /* Scratch bytes pfa_fa3_fwd can use for `a`: 0 without a mask; with key_mask or mask, 8 bytes per un-broadcast mask row and
- * 64-key tile -- pfa_fa3_fwd first condenses the mask into one 64-bit word per row and tile there (one word read per tile
- * instead of a mask byte per score: 2-4 x faster).  Optional: with workspace == NULL or too few bytes the mask is read
- * byte-wise and the result is the same. */
+ * 64-key tile (+ 128 bytes per 256 mask rows) -- pfa_fa3_fwd first condenses the mask into one 64-bit word per row and tile
+ * there (one word read per tile instead of a mask byte per score: 2-4 x faster) and notes, per 256 rows, the first and last
+ * tile that holds a visible key: a Q block then runs only those tiles, so a structured mask (a band, a triangle, padding)
+ * skips what it hides.  Optional: with workspace == NULL or too few bytes the mask is read byte-wise, every tile runs, and
+ * the result is the same. */
 size_t pfa_fa3_workspace_bytes(const pfa_fa3_args* a);
 
 /* Validate `a` without launching: PFA_OK or the error pfa_fa3_fwd would return. */
