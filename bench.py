@@ -258,8 +258,33 @@ def main():
 
     # ---- the single gather at the end (outside the timed steps) + overlapped end-to-end loop --------------
     gather = end_to_end = None
+    watchdog = None
     if world > 1:
-        try:   # secondary measurements must never cost the headline line
+        # Secondary measurements must never cost the headline line -- not even by HANGING (a collective or an IPC mapping that never
+        # returns on hardware this code has only met in a CPU rehearsal): if the gather legs are not through in 180 s, rank 0 prints the
+        # line without them and every rank leaves.
+        import threading
+
+        def _give_up():
+            if rank == 0:
+                ach = f_rank / (kern_ms * 1e-3) / 1e12
+                print(json.dumps({
+                    "metric": "attention_fwd_tflops", "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": world, "steps": args.steps,
+                    "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+                    "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                    "config": {"workload": f"{args.workload}: B={B}/GPU S={S} H={H} D={D} bf16 {'causal' if causal else 'non-causal'} "
+                                           f"(BASELINE.json {what})", "global_batch": B * world, "seq_len": S, "heads": H, "head_dim": D,
+                               "causal": causal, "sharding": f"batch x head over {world} rank(s), no data-path collective"},
+                    "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic(args.workload)[0],
+                                 "kernel_ms": round(kern_ms, 4)},
+                    "gather": {"error": "watchdog: the gather legs did not finish within 180 s; the timed steps above were complete"}}),
+                    flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(180.0, _give_up)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
             src = out if backend == "nccl" else out.cpu()
             gather = {"bytes_per_rank": out.numel() * out.element_size(), "backend": backend}
             algos = [a_ for a_ in sharded.GATHER_ALGOS if a_ != "sdma" or backend == "nccl"]      # (copy engines: device tensors only)
@@ -292,6 +317,7 @@ def main():
                 end_to_end["sdma_value"] = round(f_rank * world / (float(t) * 1e-3) / 1e12, 2)
         except Exception as exc:   # noqa: BLE001
             gather = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        watchdog.cancel()
 
     # ---- 2b. ceiling probe, same process, clocks settled: what the matrix pipes of THIS device deliver under the tile loop's MFMA + LDS
     # load on random operands without its softmax (csrc/pfa_probe.hip).  The chip lowers its clock under MFMA load, so the nominal
