@@ -226,9 +226,16 @@ typedef struct pfa_fa3_bwd_args {
     float   drop_scale;
     int32_t kv_group;           /* ABI v7 (was reserved1, must-be-0): grouped-query heads as in pfa_fa3_args.kv_group -- k, v, dk, dv hold
                                  * H / kv_group heads; dK / dV are summed over each group inside the kernel.  0 or 1 = none.  16-bit operands only. */
+    /* ABI v7: optional scratch for an ELEMENT mask (16-bit operands; ignored for key-only masks): pfa_fa3_bwd_mask_workspace_bytes()
+     * bytes.  pfa_fa3_bwd condenses the mask there into a word per row and 64-key tile, the same transposed (a word per key and 64-row
+     * tile) and the tile ranges that hold visible entries: the kernels then read one word per tile instead of a mask byte per score and
+     * run only the tiles a structured mask (a band, a triangle, documents) leaves visible.  NULL / too small: the byte paths, same result. */
+    void*   mask_workspace;
+    size_t  mask_workspace_bytes;
 } pfa_fa3_bwd_args;
 
 size_t pfa_fa3_bwd_workspace_bytes(const pfa_fa3_bwd_args* a);
+size_t pfa_fa3_bwd_mask_workspace_bytes(const pfa_fa3_bwd_args* a);
 int pfa_fa3_bwd(const pfa_fa3_bwd_args* a, void* stream);
 
 /*

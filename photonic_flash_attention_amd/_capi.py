@@ -24,7 +24,7 @@ LIB_PATH = os.path.join(_PKG_DIR, "libpfa_hip.so")
 EXPORTS = (
     "pfa_abi_version", "pfa_status_string", "pfa_device_supported", "pfa_last_hip_error",
     "pfa_fa3_workspace_bytes", "pfa_fa3_check", "pfa_fa3_fwd", "pfa_fa3_describe", "pfa_fa3_weights",
-    "pfa_fa3_bwd", "pfa_fa3_bwd_workspace_bytes", "pfa_fa3_prepare", "pfa_probe_mfma",
+    "pfa_fa3_bwd", "pfa_fa3_bwd_workspace_bytes", "pfa_fa3_bwd_mask_workspace_bytes", "pfa_fa3_prepare", "pfa_probe_mfma",
 )
 
 
@@ -61,6 +61,7 @@ class PfaFa3BwdArgs(C.Structure):
         + [("softmax_scale", C.c_float), ("device_id", C.c_int32)]
         + [("mask", C.c_void_p)] + [(f"mask_stride_{a}", C.c_int64) for a in "bhqk"]
         + [("drop_mask", C.c_void_p), ("drop_scale", C.c_float), ("kv_group", C.c_int32)]
+        + [("mask_workspace", C.c_void_p), ("mask_workspace_bytes", C.c_size_t)]
     )
 
 
@@ -109,6 +110,8 @@ def load(path: Optional[str] = None):
         lib.pfa_fa3_bwd.argtypes = [C.POINTER(PfaFa3BwdArgs), C.c_void_p]
         lib.pfa_fa3_bwd_workspace_bytes.restype = C.c_size_t
         lib.pfa_fa3_bwd_workspace_bytes.argtypes = [C.POINTER(PfaFa3BwdArgs)]
+        lib.pfa_fa3_bwd_mask_workspace_bytes.restype = C.c_size_t
+        lib.pfa_fa3_bwd_mask_workspace_bytes.argtypes = [C.POINTER(PfaFa3BwdArgs)]
         lib.pfa_fa3_describe.restype = C.c_int
         lib.pfa_fa3_describe.argtypes = [C.POINTER(PfaFa3Args), C.c_char_p, C.c_size_t]
         lib.pfa_fa3_prepare.restype = C.c_int

@@ -41,6 +41,19 @@ struct BwdParams {
     int64_t dq_sb, dq_sh, dq_ss, dk_sb, dk_sh, dk_ss, dv_sb, dv_sh, dv_ss;
     int32_t B, H, Sq, Sk;
     int32_t nblk;          // Q blocks (dq) or key blocks (dkdv)
+    // element mask condensed by pfa_fa3_bwd into `mask_workspace` (null: the byte paths below): a word per mask row and 64-key tile + the
+    // first / last key tile with a visible key per 256 rows (dQ kernel); the same transposed -- a word per key and 64-row tile + the
+    // first / last row tile per 128 keys (dK/dV kernel).  Word strides / pair strides, 0 = broadcast; RANGE_PARTS pairs per granule.
+    const unsigned long long* mw_row = nullptr;
+    int64_t mw_sb = 0, mw_sh = 0, mw_sq = 0;
+    const int* rg_row = nullptr;
+    int64_t rg_sb = 0, rg_sh = 0;
+    int32_t rg_q = 0;
+    const unsigned long long* mw_col = nullptr;
+    int64_t cw_sb = 0, cw_sh = 0;
+    int32_t ntq = 0;
+    const int* rg_col = nullptr;
+    int64_t crg_sb = 0, crg_sh = 0;
     int32_t kv_group;      // >= 1: query heads per K/V head (k, v, dk, dv hold H / kv_group heads; query head h uses K/V head h / kv_group)
     // a mask that depends on the key only ([B,Sk]: strides over heads and rows are 0) needs no KMASK kernels: the dK/dV kernel folds it
     // into its per-lane "this key exists" flag, the dQ kernel reads it four keys per load
@@ -267,7 +280,21 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
     if (p.seqlens_k) kv_len = min(kv_len, max(p.seqlens_k[b], 0));
     const int kv_end = CAUSAL ? min(kv_len, q0 + BLOCK_M) : kv_len;
     const int wave_kv_end = CAUSAL ? min(kv_len, wave_q0 + WAVE_M) : kv_len;
-    const int nt = (kv_end + BLOCK_N - 1) / BLOCK_N;
+    int nt = (kv_end + BLOCK_N - 1) / BLOCK_N;
+    int j0 = 0;                              // first key tile of the block (element mask: the tile range of its 256 rows)
+    if constexpr (KMASK) {
+        if (p.rg_row) {
+            const int* rg = p.rg_row + 2 * RANGE_PARTS * ((int64_t)b * p.rg_sb + (int64_t)hh * p.rg_sh + (p.rg_q ? (q0 >> 8) : 0));
+            int lo = rg[2 * (lane & (RANGE_PARTS - 1))], hi = rg[2 * (lane & (RANGE_PARTS - 1)) + 1];
+#pragma unroll
+            for (int off = RANGE_PARTS / 2; off >= 1; off >>= 1) {
+                lo = min(lo, __shfl_xor(lo, off));
+                hi = max(hi, __shfl_xor(hi, off));
+            }
+            nt = max(min(nt, __builtin_amdgcn_readfirstlane(hi) + 1), 0);
+            j0 = min(__builtin_amdgcn_readfirstlane(lo), nt) & ~1;
+        }
+    }
 
     const T* qp = (const T*)p.q + (int64_t)b * p.q_sb + (int64_t)hh * p.q_sh;
     const T* gp = (const T*)p.dout + (int64_t)b * p.do_sb + (int64_t)hh * p.do_sh;
@@ -284,6 +311,10 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
         gf[ks] = *(const v8*)(gp + (int64_t)qrow * p.do_ss + 16 * ks + 8 * h);
     }
     const uint8_t* mrow = KMASK ? p.mask + (int64_t)b * p.m_sb + (int64_t)hh * p.m_sh + (int64_t)qrow * p.m_sq : nullptr;
+    // the row's mask words, one per key tile; the word of tile j + 1 is requested at the top of step j, ahead of that step's DMA pieces,
+    // so the wait hipcc puts in front of its use never holds the K/V prefetch up (the byte / dword loads inside `compute` did)
+    const unsigned long long* mwrow = (KMASK && p.mw_row) ? p.mw_row + (int64_t)b * p.mw_sb + (int64_t)hh * p.mw_sh + (int64_t)qrow * p.mw_sq : nullptr;
+    unsigned long long cur_bits = ~0ull, next_bits = ~0ull;
     const int64_t stat = ((int64_t)b * p.H + hh) * p.Sq + qrow;
     const float lse = p.lse[stat];
     // delta = rowsum(dO o O) of this lane's row, computed here (this kernel holds the dO row anyway; the lane pair (l, l^32)
@@ -349,13 +380,14 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
-        // masks only where a tile crosses the diagonal or the key tail (wave-uniform, a real branch)
-        if (KMASK || p.keymask || (key_base + BLOCK_N > kv_len) || (CAUSAL && key_base + BLOCK_N - 1 > wave_q0)) {
+        // masks only where a tile crosses the diagonal or the key tail (wave-uniform, a real branch); mask words: only where a row hides a key
+        const bool word_all = mwrow && __builtin_amdgcn_ballot_w64(cur_bits != ~0ull) == 0;
+        if ((KMASK && !word_all) || p.keymask || (key_base + BLOCK_N > kv_len) || (CAUSAL && key_base + BLOCK_N - 1 > wave_q0)) {
             asm volatile("" ::: "memory");
             // key-only mask: the lane's 32 keys of the tile are 8 groups of 4 consecutive keys = 8 dword loads (the same for the 32
             // lanes of a half-wave), where the element-mask path reads a byte per score.  Keys past Sk: the key < kv_len test.
             uint32_t kmw[2][4];
-            const bool dwords = p.keymask || (KMASK && p.mask_dw);
+            const bool dwords = !mwrow && (p.keymask || (KMASK && p.mask_dw));
             if (dwords) {
                 const uint8_t* kmrow = p.keymask ? p.keymask + (int64_t)b * p.km_sb : mrow;
 #pragma unroll
@@ -371,7 +403,8 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
                     const int key = key_base + 32 * kb + (e & 3) + 8 * (e >> 2) + 4 * h;
                     bool ok = key < kv_len;
                     if (CAUSAL) ok = ok && (key <= my_q);
-                    if (dwords) ok = ok && (((kmw[kb][e >> 2] >> (8 * (e & 3))) & 0xFFu) != 0);
+                    if (mwrow) ok = ok && (((cur_bits >> (32 * kb + 4 * h + (e & 3) + 8 * (e >> 2))) & 1ull) != 0ull);
+                    else if (dwords) ok = ok && (((kmw[kb][e >> 2] >> (8 * (e & 3))) & 0xFFu) != 0);
                     else if (KMASK) ok = ok && (mrow[(int64_t)min(key, p.Sk - 1) * p.m_sk] != 0);
                     s[kb][e] = ok ? s[kb][e] : -INFINITY;
                 }
@@ -408,15 +441,26 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
     };
     auto step = [&](auto bufc, int j) {
         constexpr int BUF = decltype(bufc)::value;
+        bool seen = true;
+        if constexpr (KMASK) {
+            if (mwrow) {
+                cur_bits = next_bits;
+                if (j + 1 < nt) next_bits = mwrow[j + 1];
+                seen = __builtin_amdgcn_ballot_w64(cur_bits != 0ull) != 0;      // no row of this wave sees a key of the tile: nothing to add
+            }
+        }
         if (j + 1 < nt)
             dma.issue(wave, j + 1, kp, p.k_ss, k_slab, smem_base + (BUF ^ 1) * BUF_BYTES, vp, p.v_ss, v_slab,
                       smem_base + (BUF ^ 1) * BUF_BYTES + TILE_BYTES);
-        if (j * BLOCK_N < wave_kv_end) compute(bufc, j * BLOCK_N);
+        if (seen && j * BLOCK_N < wave_kv_end) compute(bufc, j * BLOCK_N);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_s_barrier();
     };
-    if (nt > 0) dma.issue(wave, 0, kp, p.k_ss, k_slab, smem_base, vp, p.v_ss, v_slab, smem_base + TILE_BYTES);
+    if (nt > j0) dma.issue(wave, j0, kp, p.k_ss, k_slab, smem_base, vp, p.v_ss, v_slab, smem_base + TILE_BYTES);
+    if constexpr (KMASK) {
+        if (mwrow && nt > j0) next_bits = mwrow[j0];
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
         asm volatile("" : "+v"(qf[ks]));
@@ -424,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void fa3_bwd_dq_kernel(const BwdParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (int j = 0; j < nt; j += 2) {
+    for (int j = j0; j < nt; j += 2) {
         step(IC<0>{}, j);
         if (j + 1 < nt) step(IC<1>{}, j + 1);
     }
@@ -473,8 +517,25 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
     // (a masked key behaves like one past kv_len: its column feeds only its own dK / dV, which are stored as zeros)
     const bool key_ok = my_key < kv_len && (!p.keymask || p.keymask[(int64_t)b * p.km_sb + min(my_key, p.Sk - 1)] != 0);
     // query tiles this block needs: causal -> rows >= k0
-    const int t_first = CAUSAL ? (k0 / BLOCK_N) : 0;
-    const int nt = (p.Sq + BLOCK_N - 1) / BLOCK_N;
+    int t_first = CAUSAL ? (k0 / BLOCK_N) : 0;
+    int nt = (p.Sq + BLOCK_N - 1) / BLOCK_N;
+    if constexpr (KMASK) {
+        if (p.rg_col) {       // element mask: the row tiles in which any key of this block is visible to any query head of the group
+            int lo = nt, hi = -1;
+            for (int gq = 0; gq < G; ++gq) {
+                const int* rg = p.rg_col + 2 * RANGE_PARTS * ((int64_t)b * p.crg_sb + (int64_t)(hh * G + gq) * p.crg_sh + kblk);
+                lo = min(lo, rg[2 * (lane & (RANGE_PARTS - 1))]);
+                hi = max(hi, rg[2 * (lane & (RANGE_PARTS - 1)) + 1]);
+            }
+#pragma unroll
+            for (int off = RANGE_PARTS / 2; off >= 1; off >>= 1) {
+                lo = min(lo, __shfl_xor(lo, off));
+                hi = max(hi, __shfl_xor(hi, off));
+            }
+            nt = max(min(nt, __builtin_amdgcn_readfirstlane(hi) + 1), 0);
+            t_first = max(t_first, min(__builtin_amdgcn_readfirstlane(lo), nt));
+        }
+    }
 
     const char* qp0 = (const char*)((const T*)p.q + (int64_t)b * p.q_sb + (int64_t)hh * G * p.q_sh);       // query head hh * G + gq: + gq * q_sh
     const char* gp0 = (const char*)((const T*)p.dout + (int64_t)b * p.do_sb + (int64_t)hh * G * p.do_sh);
@@ -507,6 +568,9 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
 
     const int krow = min(my_key, p.Sk - 1);
     const uint8_t* mcol0 = KMASK ? p.mask + (int64_t)b * p.m_sb + (int64_t)hh * G * p.m_sh + (int64_t)krow * p.m_sk : nullptr;     // + gq * m_sh
+    // the key's transposed mask words, one per 64-row tile (+ gq * cw_sh); the next tile's word is requested a step ahead (see the dQ kernel)
+    const unsigned long long* mcw0 = (KMASK && p.mw_col) ? p.mw_col + (int64_t)b * p.cw_sb + (int64_t)hh * G * p.cw_sh + (int64_t)krow * p.ntq : nullptr;
+    unsigned long long cur_cb = ~0ull, next_cb = ~0ull;
     v8 kf[KS], vf[KS];                       // K^T / V^T B-operand fragments: lane (key r, h) holds X[key][16ks+8h..+7]
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -552,11 +616,13 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
         // under them; read where they are used, each half paid a full memory round trip
         uint32_t mbyte[16];
         if constexpr (KMASK) {
-            const uint8_t* mcol = mcol0 + (int64_t)gq * p.m_sh;
+            if (!mcw0) {
+                const uint8_t* mcol = mcol0 + (int64_t)gq * p.m_sh;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int qi = min(q_base + (e & 3) + 8 * (e >> 2) + 4 * h, p.Sq - 1);
-                mbyte[e] = mcol[(int64_t)qi * p.m_sq];
+                for (int e = 0; e < 16; ++e) {
+                    const int qi = min(q_base + (e & 3) + 8 * (e >> 2) + 4 * h, p.Sq - 1);
+                    mbyte[e] = mcol[(int64_t)qi * p.m_sq];
+                }
             }
         }
         // (a pinned prefetch ring as in the dQ kernel costs 20 spilled registers here and doubles the run time: the two
@@ -577,9 +643,17 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
 #pragma unroll
             for (int e = 0; e < 16; ++e) s[e] = (t <= (e & 3) + 8 * (e >> 2)) ? s[e] : -INFINITY;
         }
-        if constexpr (KMASK) {                  // element mask: column my_key, rows of this half (bytes fetched before the MFMAs above)
+        if constexpr (KMASK) {                  // element mask: column my_key, rows of this half (words: bits 32 hc + ...; bytes: fetched before the MFMAs above)
+            if (mcw0) {
+                const uint32_t hb = (uint32_t)(cur_cb >> (32 * decltype(hc)::value + 4 * h));
+                if (__builtin_amdgcn_ballot_w64((hb & 0x0F0F0F0Fu) != 0x0F0F0F0Fu) != 0) {      // (all sixteen visible for every key: nothing to do)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s[e] = (mbyte[e] != 0) ? s[e] : -INFINITY;
+                    for (int e = 0; e < 16; ++e) s[e] = ((hb >> ((e & 3) + 8 * (e >> 2))) & 1u) ? s[e] : -INFINITY;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[e] = (mbyte[e] != 0) ? s[e] : -INFINITY;
+            }
         }
         // dV^T[d][key] += dO^T[d][q] P[q][key] ;  dK^T[d][key] += Q^T[d][q] dS[q][key]   (16 query rows per s2)
         static_for<2>([&](auto s2c) {
@@ -631,6 +705,15 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
             nxt_j = t_first;
             ++nxt_g;
         }
+        bool live0 = true, live1 = true;       // does any key of this wave see a row of the tile's halves? (element-mask words)
+        if constexpr (KMASK) {
+            if (mcw0) {
+                cur_cb = next_cb;
+                if (more) next_cb = mcw0[(int64_t)nxt_g * p.cw_sh + nxt_j];
+                live0 = __builtin_amdgcn_ballot_w64((uint32_t)cur_cb != 0u) != 0;
+                live1 = __builtin_amdgcn_ballot_w64((uint32_t)(cur_cb >> 32) != 0u) != 0;
+            }
+        }
         if (more) {
             dma.issue(wave, nxt_j, qp0 + (int64_t)nxt_g * p.q_sh * 2, p.q_ss, q_slab, smem_base + (BUF ^ 1) * BUF_BYTES,
                       gp0 + (int64_t)nxt_g * p.do_sh * 2, p.do_ss, g_slab, smem_base + (BUF ^ 1) * BUF_BYTES + TILE_BYTES);
@@ -638,8 +721,8 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
         }
         const int q_base = cur_j * BLOCK_N;
         // causal: a 32-row half whose last row is above this wave's first key contributes nothing
-        if (!CAUSAL || q_base + 31 >= wave_k0) half(bufc, IC<0>{}, q_base, cur_g);
-        if (q_base + 32 < p.Sq && (!CAUSAL || q_base + 63 >= wave_k0)) half(bufc, IC<1>{}, q_base + 32, cur_g);
+        if (live0 && (!CAUSAL || q_base + 31 >= wave_k0)) half(bufc, IC<0>{}, q_base, cur_g);
+        if (live1 && q_base + 32 < p.Sq && (!CAUSAL || q_base + 63 >= wave_k0)) half(bufc, IC<1>{}, q_base + 32, cur_g);
         if (more) stat_store(BUF ^ 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -651,6 +734,9 @@ __global__ __launch_bounds__(256, 2) void fa3_bwd_dkdv_kernel(const BwdParams p)
         dma.issue(wave, t_first, qp0, p.q_ss, q_slab, smem_base, gp0, p.do_ss, g_slab, smem_base + TILE_BYTES);
         stat_load(0, t_first);
         stat_store(0);
+        if constexpr (KMASK) {
+            if (mcw0) next_cb = mcw0[t_first];
+        }
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {

@@ -341,11 +341,11 @@ __global__ __launch_bounds__(256) void fa3_maskbits16_kernel(const uint8_t* m, i
 // first / last tile with a visible key per 256 mask rows (see FwdParams::mrange): RANGE_PARTS workgroups per granule and mask (batch, head),
 // each leaves the pair of its share of the rows; the forward kernel takes the minimum / maximum of the parts
 constexpr int RANGE_PARTS = 16;
-template <int UNUSED = 0>
+template <int GRAN = 256>      // rows per granule: 256 (a Q block of the forward / dQ kernels) or 128 (a key block of the dK/dV kernel, on transposed words)
 __global__ __launch_bounds__(256) void fa3_maskrange_kernel(const unsigned long long* words, int64_t ob, int64_t oh, int64_t oq, int Hm, int Qm,
                                                            int nt, int* out, int ngran) {
     const int g = blockIdx.x / RANGE_PARTS, part = blockIdx.x - g * RANGE_PARTS, b = blockIdx.y / Hm, hh = blockIdx.y - b * Hm;
-    const int r0 = min(Qm, g * 256 + part * (256 / RANGE_PARTS)), r1 = min(Qm, r0 + 256 / RANGE_PARTS);
+    const int r0 = min(Qm, g * GRAN + part * (GRAN / RANGE_PARTS)), r1 = min(Qm, r0 + GRAN / RANGE_PARTS);
     const unsigned long long* w = words + (int64_t)b * ob + (int64_t)hh * oh;
     int lo = nt, hi = -1;
     for (int idx = threadIdx.x; idx < (r1 - r0) * nt; idx += 256) {
@@ -371,6 +371,26 @@ __global__ __launch_bounds__(256) void fa3_maskrange_kernel(const unsigned long 
         o[0] = min(min(slo[0], slo[1]), min(slo[2], slo[3]));
         o[1] = max(max(shi[0], shi[1]), max(shi[2], shi[3]));
     }
+}
+
+// The words transposed, for the key-stationary dK/dV kernel: bit i of word (b, h, key, tq) = row 64 tq + i sees `key`.  One wave per
+// (64 rows, 64 keys): a lane holds its row's word of the key tile, 64 ballots turn the bit matrix over.  rows = the mask's own row
+// extent (1: every row alike), Sq = the problem's.
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void fa3_maskbitsT_kernel(const unsigned long long* roww, int64_t ob, int64_t oh, int64_t oq, int Hm, int rows,
+                                                           int Sq, int Sk, int nt, int ntq, unsigned long long* colw) {
+    const int lane = threadIdx.x & 63, kt = blockIdx.x * 4 + (threadIdx.x >> 6), tq = blockIdx.y;
+    const int b = blockIdx.z / Hm, hh = blockIdx.z - b * Hm;
+    if (kt >= nt) return;
+    const int row = 64 * tq + lane;
+    const unsigned long long w = row < Sq ? roww[(int64_t)b * ob + (int64_t)hh * oh + (int64_t)(rows > 1 ? row : 0) * oq + kt] : 0ull;
+    unsigned long long kept = 0ull;
+    for (int c = 0; c < 64; ++c) {
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(((w >> c) & 1ull) != 0ull);
+        if (lane == c) kept = bal;
+    }
+    const int key = 64 * kt + lane;
+    if (key < Sk) colw[(((int64_t)b * Hm + hh) * Sk + key) * ntq + tq] = kept;
 }
 
 template <typename T, int D, bool CAUSAL, bool SPLITP, bool KMASK, int VAR, typename OT>

@@ -90,7 +90,31 @@ void pick_kernels(bool causal, bool kmask, bool g32, const void*& delta, const v
 
 }  // namespace
 
+// geometry of the condensed element mask in pfa_fa3_bwd_args.mask_workspace (see BwdParams): [row words][row ranges][column words][column ranges]
+struct BwdMaskWs {
+    int Bm = 0, Hm = 0, Qm = 0, nt = 0, ntq = 0, ngq = 0, nkb = 0;
+    size_t roww = 0, rowr = 0, colw = 0, colr = 0;
+    size_t bytes() const { return roww + rowr + colw + colr; }
+};
+static BwdMaskWs bwd_mask_ws(const pfa_fa3_bwd_args* a) {
+    BwdMaskWs w;
+    if (!a || !a->mask || a->dtype == PFA_DTYPE_FP32) return w;
+    if (a->mask_stride_h == 0 && a->mask_stride_q == 0) return w;              // key-only masks never reach the element-mask kernels
+    w.Bm = a->mask_stride_b ? a->B : 1; w.Hm = a->mask_stride_h ? a->H : 1; w.Qm = a->mask_stride_q ? a->Sq : 1;
+    if (w.Qm > 65535 || (int64_t)w.Bm * w.Hm > 65535) return BwdMaskWs();     // launch limits: the byte paths serve these
+    w.nt = (a->Sk + 63) / 64; w.ntq = (a->Sq + 63) / 64;
+    if (w.ntq > 65535) return BwdMaskWs();
+    w.ngq = (w.Qm + 255) / 256; w.nkb = (a->Sk + 127) / 128;
+    const size_t bh = (size_t)w.Bm * w.Hm;
+    w.roww = bh * w.Qm * w.nt * 8; w.rowr = bh * w.ngq * pfa::RANGE_PARTS * 8;
+    w.colw = bh * (size_t)a->Sk * w.ntq * 8; w.colr = bh * w.nkb * pfa::RANGE_PARTS * 8;
+    return w;
+}
+
 extern "C" {
+
+size_t pfa_fa3_bwd_mask_workspace_bytes(const pfa_fa3_bwd_args* a) { return bwd_mask_ws(a).bytes(); }
+
 
 size_t pfa_fa3_bwd_workspace_bytes(const pfa_fa3_bwd_args* a) {
     if (!a || a->B <= 0 || a->H <= 0 || a->Sq <= 0) return 0;
@@ -160,6 +184,20 @@ int pfa_fa3_bwd(const pfa_fa3_bwd_args* a, void* stream) {
                  a->mask_stride_q % 4 == 0 && ((uintptr_t)a->mask & 3) == 0) ? 1 : 0;
     p.scale = a->softmax_scale;
     p.scale_log2 = a->softmax_scale * 1.4426950408889634f;
+    // element mask + scratch: words, transposed words and tile ranges (launched below, in front of the two kernels)
+    const BwdMaskWs mw = p.mask ? bwd_mask_ws(a) : BwdMaskWs();
+    const bool use_words = mw.bytes() > 0 && a->mask_workspace && a->mask_workspace_bytes >= mw.bytes();
+    if (use_words) {
+        char* ws = (char*)a->mask_workspace;
+        p.mw_row = (const unsigned long long*)ws;
+        p.mw_sq = mw.Qm > 1 ? mw.nt : 0; p.mw_sh = mw.Hm > 1 ? (int64_t)mw.Qm * mw.nt : 0; p.mw_sb = mw.Bm > 1 ? (int64_t)mw.Hm * mw.Qm * mw.nt : 0;
+        p.rg_row = (const int*)(ws + mw.roww);
+        p.rg_q = mw.Qm > 1 ? 1 : 0; p.rg_sh = mw.Hm > 1 ? mw.ngq : 0; p.rg_sb = mw.Bm > 1 ? (int64_t)mw.Hm * mw.ngq : 0;
+        p.mw_col = (const unsigned long long*)(ws + mw.roww + mw.rowr);
+        p.ntq = mw.ntq; p.cw_sh = mw.Hm > 1 ? (int64_t)a->Sk * mw.ntq : 0; p.cw_sb = mw.Bm > 1 ? (int64_t)mw.Hm * a->Sk * mw.ntq : 0;
+        p.rg_col = (const int*)(ws + mw.roww + mw.rowr + mw.colw);
+        p.crg_sh = mw.Hm > 1 ? mw.nkb : 0; p.crg_sb = mw.Bm > 1 ? (int64_t)mw.Hm * mw.nkb : 0;
+    }
 
     const void *kdelta, *kdq, *kdkdv;
     const bool causal = a->causal != 0, g32 = a->dtype_grad == PFA_DTYPE_FP32, kmask = p.mask != nullptr;     // (not for key-only masks)
@@ -185,6 +223,33 @@ int pfa_fa3_bwd(const pfa_fa3_bwd_args* a, void* stream) {
     //  fa3_bwd_delta_kernel is kept for reference / diagnostics but is no longer launched)
     (void)kdelta;
     (void)rows_per_block;
+    if (use_words) {
+        char* ws = (char*)a->mask_workspace;
+        const dim3 bh((unsigned)1, (unsigned)1, (unsigned)(mw.Bm * mw.Hm));
+        const bool wide = a->mask_stride_k == 1 && a->Sk % 16 == 0 && a->mask_stride_b % 16 == 0 && a->mask_stride_h % 16 == 0 &&
+                          a->mask_stride_q % 16 == 0 && ((uintptr_t)a->mask & 15) == 0;
+        if (wide)
+            hipLaunchKernelGGL(pfa::fa3_maskbits16_kernel<0>, dim3((unsigned)(((mw.nt + 15) / 16 + 3) / 4), (unsigned)mw.Qm, bh.z), dim3(256), 0,
+                               (hipStream_t)stream, a->mask, a->mask_stride_b, a->mask_stride_h, a->mask_stride_q, mw.Hm, a->Sk, mw.nt,
+                               (unsigned long long*)ws, p.mw_sb, p.mw_sh, p.mw_sq);
+        else
+            hipLaunchKernelGGL(pfa::fa3_maskbits_kernel<0>, dim3((unsigned)((mw.nt + 3) / 4), (unsigned)mw.Qm, bh.z), dim3(256), 0, (hipStream_t)stream,
+                               a->mask, a->mask_stride_b, a->mask_stride_h, a->mask_stride_q, a->mask_stride_k, mw.Hm, a->Sk, mw.nt,
+                               (unsigned long long*)ws, p.mw_sb, p.mw_sh, p.mw_sq);
+        hipLaunchKernelGGL(pfa::fa3_maskrange_kernel<256>, dim3((unsigned)(mw.ngq * pfa::RANGE_PARTS), bh.z), dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned long long*)ws, p.mw_sb, p.mw_sh, p.mw_sq, mw.Hm, mw.Qm, mw.nt, (int*)(ws + mw.roww), mw.ngq);
+        // (the transposed words always have the problem's own row count: a mask without a row dimension is the same word in every row)
+        hipLaunchKernelGGL(pfa::fa3_maskbitsT_kernel<0>, dim3((unsigned)((mw.nt + 3) / 4), (unsigned)mw.ntq, bh.z), dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned long long*)ws, p.mw_sb, p.mw_sh, p.mw_sq, mw.Hm, mw.Qm, a->Sq, a->Sk, mw.nt, mw.ntq,
+                           (unsigned long long*)(ws + mw.roww + mw.rowr));
+        hipLaunchKernelGGL(pfa::fa3_maskrange_kernel<128>, dim3((unsigned)(mw.nkb * pfa::RANGE_PARTS), bh.z), dim3(256), 0, (hipStream_t)stream,
+                           (const unsigned long long*)(ws + mw.roww + mw.rowr), (int64_t)mw.Hm * a->Sk * mw.ntq, (int64_t)a->Sk * mw.ntq,
+                           (int64_t)mw.ntq, mw.Hm, a->Sk, mw.ntq, (int*)(ws + mw.roww + mw.rowr + mw.colw), mw.nkb);
+        if (hipGetLastError() != hipSuccess) {
+            if (prev != a->device_id) (void)hipSetDevice(prev);
+            return PFA_ERR_LAUNCH;
+        }
+    }
     p.nblk = (a->Sq + 255) / 256;
     e = hipLaunchKernel(kdq, dim3((unsigned)(p.nblk * BH)), dim3(512), args, (size_t)lds, (hipStream_t)stream);
     if (e == hipSuccess) {

@@ -286,7 +286,7 @@ static bool launch_mask_bits(const MaskBits& mb, const pfa_fa3_args* a, void* st
                            (hipStream_t)stream, mb.src, mb.sb, mb.sh, mb.sq, mb.sk, mb.Hm, a->Sk, mb.nt, (unsigned long long*)a->workspace,
                            mb.ob, mb.oh, mb.oq);
     if (hipGetLastError() != hipSuccess) return false;
-    hipLaunchKernelGGL(pfa::fa3_maskrange_kernel<0>, dim3((unsigned)(mb.ngran * pfa::RANGE_PARTS), (unsigned)(mb.Bm * mb.Hm)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(pfa::fa3_maskrange_kernel<256>, dim3((unsigned)(mb.ngran * pfa::RANGE_PARTS), (unsigned)(mb.Bm * mb.Hm)), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned long long*)a->workspace, mb.ob, mb.oh, mb.oq, mb.Hm, mb.Qm, mb.nt,
                        (int*)((char*)a->workspace + mb.word_bytes()), mb.ngran);
     return hipGetLastError() == hipSuccess;

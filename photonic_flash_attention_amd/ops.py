@@ -368,6 +368,12 @@ def fa3_backward(q, k, v, out, dout, lse, *, causal: bool = False, seqlens_k=Non
     a.softmax_scale = float(D ** -0.5 if softmax_scale is None else softmax_scale)
     a.device_id = q.device.index if q.device.index is not None else torch.cuda.current_device()
     stream = torch.cuda.current_stream(q.device)
+    if a.mask:   # element masks: scratch for the condensed words / tile ranges (0 bytes for key-only masks; optional for the library)
+        mws = int(_capi.load().pfa_fa3_bwd_mask_workspace_bytes(C.byref(a)))
+        if mws:
+            ws = torch.empty(mws, dtype=torch.uint8, device=q.device)
+            a.mask_workspace, a.mask_workspace_bytes = ws.data_ptr(), mws
+            keep.append(ws)
     st = _capi.load().pfa_fa3_bwd(C.byref(a), C.c_void_p(stream.cuda_stream))
     if st in (-3, -4, -5, -6, -7, -10):
         raise ValueError(f"pfa_fa3_bwd: {_capi.status_string(st)}")

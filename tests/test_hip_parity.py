@@ -1191,3 +1191,56 @@ def test_element_masks_skip_the_tiles_they_hide(case):
         assert bool((torch.isinf(l_) == dead).all())
         assert float((l_ - ref_lse)[~dead].abs().max()) <= 1e-4
     assert bool((o16.float().cpu()[dead] == 0).all())
+
+
+@pytest.mark.parametrize("case", [("window", 1, 4, 2, 1024, 1024, 128), ("documents", 2, 2, 1, 1280, 1280, 64), ("dead_block", 1, 2, 1, 768, 1024, 128),
+                                  ("per_head", 1, 4, 2, 512, 640, 64), ("ragged_band", 2, 3, 1, 333, 777, 128)])
+def test_backward_element_masks_words_and_tile_ranges(case):
+    """Backward under an element mask with `mask_workspace` (ops gives it): the dQ kernel reads a word per row and key tile, the dK/dV
+    kernel the transposed word per key and row tile, both run only the tile range that holds visible entries (and with grouped-query
+    heads the union over the group).  Structured masks against autograd through a torch fp32 reference; also against the byte paths
+    (no workspace), which must agree bit for bit."""
+    import ctypes as C
+    from photonic_flash_attention_amd import _capi, ops, synth
+    kind, B, H, G, Sq, Sk, D = case
+    q, k, v = (t.to("cuda:0").permute(0, 2, 1, 3) for t in synth.qkv(B, H, Sq, Sk, D, 8100 + Sq + D, "bf16"))
+    k, v = k[:, ::G], v[:, ::G]
+    g = torch.from_numpy(synth.normal_f32((B, Sq, H, D), 8200 + Sq)).to("cuda:0", q.dtype).permute(0, 2, 1, 3)
+    iq, ik = torch.arange(Sq, device="cuda:0")[:, None], torch.arange(Sk, device="cuda:0")[None, :]
+    if kind == "window":
+        keep = ((iq - ik >= 0) & (iq - ik < 150)).view(1, 1, Sq, Sk)
+    elif kind == "documents":
+        keep = torch.zeros(B, 1, Sq, Sk, dtype=torch.bool, device="cuda:0")
+        for b_, cuts in enumerate([(0, 300, 1000, 1280), (0, 64, 65, 1280)][:B]):
+            for a0, a1 in zip(cuts[:-1], cuts[1:]):
+                keep[b_, 0, a0:a1, a0:a1] = True
+    elif kind == "dead_block":
+        keep = torch.zeros(1, 1, Sq, Sk, dtype=torch.bool, device="cuda:0")
+        keep[..., :256, 300:700] = True
+        keep[..., 512:, 650:1024] = True
+    elif kind == "per_head":
+        keep = torch.zeros(1, H, Sq, Sk, dtype=torch.bool, device="cuda:0")
+        for h_ in range(H):
+            keep[0, h_, :, 100 * h_:100 * h_ + 250] = True
+    else:
+        keep = ((ik >= iq // 2) & (ik < iq // 2 + 300)).view(1, 1, Sq, Sk).expand(B, 1, Sq, Sk).clone()
+        keep[1, :, :100] = False
+    out, lse = ops.fa3_forward(q, k, v, mask=keep, return_lse=True)
+    dq, dk, dv = ops.fa3_backward(q, k, v, out, g, lse, mask=keep, grad_dtype=torch.float32)
+    # the same call without the scratch: the byte paths
+    orig = _capi.load().pfa_fa3_bwd_mask_workspace_bytes
+    try:
+        _capi.load().pfa_fa3_bwd_mask_workspace_bytes = lambda *_a: 0
+        dq_b, dk_b, dv_b = ops.fa3_backward(q, k, v, out, g, lse, mask=keep, grad_dtype=torch.float32)
+    finally:
+        _capi.load().pfa_fa3_bwd_mask_workspace_bytes = orig
+    torch.cuda.synchronize()
+    assert torch.equal(dq, dq_b) and torch.equal(dk, dk_b) and torch.equal(dv, dv_b), case
+    qf, kf, vf = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    ke, ve = kf.repeat_interleave(G, dim=1), vf.repeat_interleave(G, dim=1)
+    s = (qf @ ke.transpose(-1, -2)) * D ** -0.5
+    p = torch.nan_to_num(torch.softmax(s.masked_fill(~keep.expand(B, H, Sq, Sk), float("-inf")), dim=-1), nan=0.0)
+    (p @ ve).backward(g.float())
+    for name, got, ref in (("dq", dq, qf.grad), ("dk", dk, kf.grad), ("dv", dv, vf.grad)):
+        scale, err = float(ref.abs().max()), float((got - ref).abs().max())
+        assert bool(torch.isfinite(got).all()) and err <= 2e-2 * scale + 1e-4, (case, name, err, scale)
