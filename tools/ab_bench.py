@@ -8,7 +8,10 @@ from photonic_flash_attention_amd import ops, _capi
 CONFIGS = {"C3": (4, 16, 4096, 128, True), "C4": (4, 16, 4096, 128, False), "C5": (1, 32, 16384, 128, True),
            "C2": (4, 12, 1024, 64, False), "S2K": (16, 16, 2048, 128, False), "S8Kc": (2, 16, 8192, 128, True),
            "S1K": (16, 16, 1024, 128, False), "S1Kc": (16, 16, 1024, 128, True), "S512": (32, 16, 512, 128, False),
-           "S512c": (32, 16, 512, 128, True), "S256": (64, 16, 256, 128, False), "S2Kc": (16, 16, 2048, 128, True)}
+           "S512c": (32, 16, 512, 128, True), "S256": (64, 16, 256, 128, False), "S2Kc": (16, 16, 2048, 128, True),
+           # few (batch, head) pairs: does the persistent kernel (one 256-row unit -- causal: a PAIR of blocks -- per CU) leave CUs idle?
+           "b1h1S4K": (1, 1, 4096, 128, False), "b1h1S4Kc": (1, 1, 4096, 128, True), "b1h4S4Kc": (1, 4, 4096, 128, True), "b1h8S2K": (1, 8, 2048, 128, False),
+           "b1h8S8Kc": (1, 8, 8192, 128, True), "b2h8S1Kc": (2, 8, 1024, 128, True), "b1h12S1Kd64": (1, 12, 1024, 64, False), "b1h16S16Kc": (1, 16, 16384, 128, True)}
 ap = argparse.ArgumentParser()
 ap.add_argument("--configs", default="C4,C3")
 ap.add_argument("--variants", default="0,1,2,3,4,5")
