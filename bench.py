@@ -444,6 +444,35 @@ def main():
                                  "kernel": _capi.describe(ops.build_args(q2v, k2v, v2v, o2v, causal=True, key_mask=km3)[0])[0],
                                  "shape": "C3 under the causal mask with a [B, Sk] key-padding mask of the same lengths (dense-equivalent flops; "
                                           "includes the two small device ops that derive the cut from the mask)"}
+        # an ELEMENT mask (flash_attention_3.py:234-236 takes any 4-D mask): a 1024-key sliding window as a [1,1,S,S] mask on the HIP kernels --
+        # condensed to mask words + the tile range each Q block can see, so the launch runs what the band leaves visible
+        try:
+            ii = torch.arange(s2, device=dev)
+            band = ((ii[:, None] - ii[None, :] >= 0) & (ii[:, None] - ii[None, :] < 1024))[None, None]
+
+            def step8():
+                ops.fa3_forward(q2v, k2v, v2v, mask=band, out=o2v)
+            for _ in range(20):
+                step8()
+            w8, kk8 = timed(step8, args.steps, 3)
+            m8 = statistics.median(kk8)
+            o8, lse8 = ops.fa3_forward(q2v, k2v, v2v, mask=band, return_lse=True)
+            g8 = torch.randn_like(o8)
+
+            def step9():
+                ops.fa3_backward(q2v, k2v, v2v, o8, g8, lse8, mask=band)
+            for _ in range(3):
+                step9()
+            w9, kk9 = timed(step9, max(2, args.steps // 4), 3)
+            others["C3_window1024_element_mask"] = {
+                "ms": round(m8, 4), "backward_ms": round(statistics.median(kk9), 4), "frac": None,
+                "tflops": round(flops(b2, h2, s2, d2, True) / (m8 * 1e-3) / 1e12, 2),
+                "kernel": _capi.describe(ops.build_args(q2v, k2v, v2v, o2v, mask=band)[0])[0],
+                "shape": "C3's shape, causal sliding window of 1024 keys given as a 4-D element mask (tflops: causal-equivalent flops, for scale; "
+                         "ms includes the two condensing kernels; backward_ms: pfa_fa3_bwd under the same mask)"}
+            del o8, lse8, g8, band
+        except Exception as exc:   # noqa: BLE001
+            others["C3_window1024_element_mask"] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
         others["C3_seqlens"] = {"ms": round(m5, 4), "tflops": round(flops(b2, h2, s2, d2, True) / (m5 * 1e-3) / 1e12, 2), "frac": None,
                                 "kernel": _capi.describe(ops.build_args(q2v, k2v, v2v, o2v, causal=True, seqlens_k=sl3)[0])[0],
                                 "shape": f"C3 with seqlens_k = {lens3} under the causal mask (dense-equivalent flops: the padding is not computed)"}
